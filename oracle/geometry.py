@@ -1,0 +1,113 @@
+"""Oracle (test infrastructure): pose / projection / inverse-warp arithmetic on CPU tensors.
+
+Restates, batch-generic and device-generic:
+  * disp_to_depth                    reference geometry/pose_geometry.py:70-95
+  * axis-angle -> rotation (Rodrigues with the +1e-7 guard)   pose_geometry.py:160-199
+  * translation matrix, T = Trans @ Rot                      pose_geometry.py:124-157
+  * rigid inverse                                             pose_geometry.py:110-115
+  * back-projection  Xc = (K^-1 [x y 1]^T) * depth            geometry/transform.py:74-105
+  * projection + normalisation to [-1, 1]                     geometry/transform.py:107-150
+  * inverse_warp = bilinear grid_sample(zeros, align_corners=True)  pose_geometry.py:201-229
+
+The reference hard-codes ``.cuda()`` (transform.py:134) and ``repeat(4, ...)`` (transform.py:110);
+the arithmetic below is the same sequence of fp32 operations without those two restrictions.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def disp_to_depth(disps):
+    """Nested list [time][scale] of sigmoid disparities -> depths, D = 1 / (10 * disp + 0.01)."""
+    return [[1 / (10 * d + 0.01) for d in per_time] for per_time in disps]
+
+
+def rotation_from_axis_angle(v):
+    """v: [B,1,3] axis-angle -> [B,4,4] homogeneous rotation (Rodrigues, axis = v / (|v| + 1e-7))."""
+    angle = torch.norm(v, 2, 2, True)              # [B,1,1]
+    axis = v / (angle + 1e-7)
+    c = torch.cos(angle)
+    s = torch.sin(angle)
+    t = 1 - c
+    x, y, z = (axis[..., i].unsqueeze(1) for i in range(3))   # each [B,1,1]
+    xs, ys, zs = x * s, y * s, z * s
+    xt, yt, zt = x * t, y * t, z * t
+    xyt, yzt, zxt = x * yt, y * zt, z * xt
+    rows = [
+        [x * xt + c, xyt - zs, zxt + ys],
+        [xyt + zs, y * yt + c, yzt - xs],
+        [zxt - ys, yzt + xs, z * zt + c],
+    ]
+    B = v.shape[0]
+    R = torch.zeros(B, 4, 4, dtype=v.dtype, device=v.device)
+    for i in range(3):
+        for j in range(3):
+            R[:, i, j] = rows[i][j].reshape(B)
+    R[:, 3, 3] = 1
+    return R
+
+
+def translation_matrix(t):
+    """t: [B,1,3] -> [B,4,4] with t in the last column."""
+    B = t.shape[0]
+    T = torch.eye(4, dtype=t.dtype, device=t.device).repeat(B, 1, 1)
+    T[:, :3, 3] = t.reshape(B, 3)
+    return T
+
+
+def pose_to_matrix(pose, invert=False):
+    """pose [B,6] = (axis-angle, translation) -> Tcw [B,4,4] = Trans @ Rot; optional rigid inverse."""
+    rot = pose[:, :3].unsqueeze(1)
+    trans = pose[:, 3:].unsqueeze(1)
+    T = torch.matmul(translation_matrix(trans), rotation_from_axis_angle(rot))
+    if invert:
+        T = invert_rigid(T)
+    return T
+
+
+def invert_rigid(T):
+    """[R | t] -> [R^T | -R^T t]  (pose_geometry.py:110-115)."""
+    Ti = torch.eye(4, dtype=T.dtype, device=T.device).repeat(len(T), 1, 1)
+    Rt = T[:, :3, :3].transpose(-2, -1)
+    Ti[:, :3, :3] = Rt
+    Ti[:, :3, 3] = torch.bmm(-1.0 * Rt, T[:, :3, 3:4]).squeeze(-1)
+    return Ti
+
+
+def pixel_grid(B, H, W, dtype, device):
+    """[B,3,H*W] homogeneous pixel coordinates (x, y, 1), built from linspace as the reference does."""
+    xs = torch.linspace(0, W - 1, W, dtype=dtype, device=device)
+    ys = torch.linspace(0, H - 1, H, dtype=dtype, device=device)
+    yy, xx = torch.meshgrid([ys, xs], indexing="ij")
+    g = torch.stack([xx, yy, torch.ones_like(xx)], 0).reshape(1, 3, H * W)
+    return g.repeat(B, 1, 1)
+
+
+def reconstruct(depth, K):
+    """depth [B,H,W], K [B,3,3] (any float dtype) -> camera points [B,3,H,W]."""
+    B, H, W = depth.shape
+    Kinv = K.inverse().float()
+    rays = Kinv.bmm(pixel_grid(B, H, W, depth.dtype, depth.device)).view(B, 3, H, W)
+    return rays * depth.unsqueeze(1)
+
+
+def project(X, K, Tcw):
+    """X [B,3,H,W], K [B,3,3], Tcw [B,4,4] -> sampling grid [B,H,W,2] in [-1,1] (x, y)."""
+    B, _, H, W = X.shape
+    Xh = torch.cat([X.view(B, 3, -1), torch.ones(B, 1, H * W, dtype=X.dtype, device=X.device)], 1)
+    K4 = torch.eye(4, device=K.device).repeat(B, 1, 1)      # float32, as the reference's torch.eye(4)
+    K4[:, :3, :3] = K
+    P = (K4 @ Tcw)[:, :3, :]
+    cam = P @ Xh
+    pix = cam[:, :2, :] / (cam[:, 2:3, :] + 1e-5)
+    pix = pix.view(B, 2, H, W).permute(0, 2, 3, 1)
+    gx = pix[..., 0] / (W - 1)
+    gy = pix[..., 1] / (H - 1)
+    return (torch.stack([gx, gy], -1) - 0.5) * 2
+
+
+def inverse_warp(img, depth, pose, K, pose_inv):
+    """Warp source image `img` [B,3,H,W] into the target view given target depth [B,H,W]."""
+    Xc = reconstruct(depth, K)
+    Tcw = pose_to_matrix(pose, invert=bool(pose_inv))
+    grid = project(Xc, K, Tcw)
+    return F.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
