@@ -1,0 +1,186 @@
+"""GPU: the HIP loss stage (through the C ABI, via the reference call surface) against the reference goldens
+and against the CPU oracle on seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(DEV) if dtype is None else t.to(DEV, dtype)
+
+
+def grad_close(got, want, frac=1e-3, l2=1e-3):
+    """L1-type losses: a handful of sign flips at |residual| ~ ulp are legitimate; everything else must agree."""
+    got = got.detach().cpu().double()
+    want = torch.as_tensor(np.asarray(want)).double()
+    scale = want.abs().max().clamp_min(1e-30)
+    bad = ((got - want).abs() > 1e-4 * scale).double().mean()
+    assert float(bad) < frac, "fraction of mismatching elements %g" % float(bad)
+    assert float((got - want).norm() / want.norm().clamp_min(1e-30)) < l2
+
+
+@pytest.mark.parametrize("up,tag", [(None, ""), ((1.0, 0.0), "_mam"), ((0.0, 1.0), "_smooth"), ((1.0, 1.0), "")])
+def test_losses_forward_backward_vs_reference_golden(golden, up, tag):
+    from losses import Losses
+    g = golden("loss_small.npz")
+    disp_t = T(g["disp_t"]).requires_grad_()
+    disp_r = T(g["disp_r"]).requires_grad_()
+    poses = T(g["poses"]).requires_grad_()
+    out = Losses().forward(T(g["tgt"]), [T(g["ref0"]), T(g["ref1"])], [[disp_t], [disp_r]], poses, T(g["K"]), None)
+    assert abs(float(out[0]) - g["loss"][0]) < 2e-6 * abs(g["loss"][0])
+    assert abs(float(out[1]) - g["loss"][1]) < 2e-6 * abs(g["loss"][1])
+    if up is None:
+        sum(out).backward()            # exactly what trainer.py:264 does
+    else:
+        (up[0] * out[0] + up[1] * out[1]).backward()
+    grad_close(disp_t.grad, g["g_disp_t" + tag])
+    want_p = g["g_poses" + tag]
+    assert float((poses.grad.cpu() - torch.from_numpy(want_p)).abs().max()) <= 1e-3 * np.abs(want_p).max() + 1e-12
+    if tag == "":
+        grad_close(disp_r.grad, g["g_disp_r"])
+
+
+def test_losses_ka1(golden):
+    from losses import Losses
+    g = golden("loss_ka1.npz")
+    torch.manual_seed(0)
+    B, H, W = 4, 64, 128
+    K = torch.tensor([[0.58 * W, 0, 0.5 * W], [0, 1.92 * H, 0.5 * H], [0, 0, 1]], dtype=torch.float64).repeat(B, 1, 1)
+    tgt = torch.randn(B, 3, H, W)
+    refs = [torch.randn(B, 3, H, W), torch.randn(B, 3, H, W)]
+    disp_t = torch.rand(B, 1, H, W)
+    disp_r = torch.rand(B, 1, H, W)
+    poses = 0.01 * torch.randn(B, 2, 6)
+    dig = np.array([float(tgt.double().sum()), float(refs[1].double().sum()), float(disp_r.double().sum()), float(poses.double().sum())])
+    assert np.allclose(dig, g["input_digest"], rtol=1e-9), "torch CPU RNG stream differs from the fixture's"
+    dt, dr, p = disp_t.to(DEV).requires_grad_(), disp_r.to(DEV).requires_grad_(), poses.to(DEV).requires_grad_()
+    out = Losses().forward(tgt.to(DEV), [r.to(DEV) for r in refs], [[dt], [dr]], p, K.to(DEV), None)
+    assert np.allclose([float(out[0]), float(out[1])], g["loss"], rtol=3e-6)
+    sum(out).backward()
+    norms = [float(dt.grad.norm()), float(dr.grad.norm()), float(p.grad.norm())]
+    assert np.allclose(norms, g["grad_norms"], rtol=2e-3)
+    assert rel_err(p.grad, g["g_poses"]) < 1e-3
+
+
+def test_inverse_warp_vs_reference_golden(golden):
+    from geometry.pose_geometry import inverse_warp
+    g = golden("loss_small.npz")
+    K, p = T(g["K"]), T(g["poses"])
+    Dt = T(g["depth_t"])
+    Dr = 1.0 / (10.0 * T(g["disp_r"])[:, 0] + 0.01)
+    assert rel_err(inverse_warp(T(g["ref0"]), Dt, p[:, 0].contiguous(), K, False), g["warp0"]) < 2e-5
+    assert rel_err(inverse_warp(T(g["ref1"]), Dt, p[:, 1].contiguous(), K, False), g["warp1"]) < 2e-5
+    assert rel_err(inverse_warp(T(g["tgt"]), Dr, p[:, 0].contiguous(), K, True), g["warp2"]) < 2e-5
+    # fp32 intrinsics take the other branch of the K loader
+    assert rel_err(inverse_warp(T(g["ref0"]), Dt, p[:, 0].contiguous(), K.float(), False), g["warp0"]) < 1e-4
+
+
+def test_inverse_warp_edges(golden):
+    from geometry.pose_geometry import inverse_warp
+    g = golden("warp_edge.npz")
+    img, K = T(g["img"]), T(g["K"])
+    B, _, H, W = img.shape
+    w_id = inverse_warp(img, torch.full((B, H, W), 5.0, device=DEV), torch.zeros(B, 6, device=DEV), K, False)
+    assert rel_err(w_id, g["warp_identity"]) < 1e-5
+    d, big = T(g["depth"]), T(g["pose_big"])
+    got = inverse_warp(img, d, big, K, False).cpu().numpy()
+    # samples that land within float rounding of the image border may flip in/out of bounds
+    for got_i, want in ((got, g["warp_big"]), (inverse_warp(img, d, big, K, True).cpu().numpy(), g["warp_big_inv"])):
+        bad = np.abs(got_i - want) > 1e-4 * np.abs(want).max()
+        assert bad.mean() < 2e-3
+
+
+def test_inverse_warp_backward_vs_oracle():
+    from geometry.pose_geometry import inverse_warp
+    from oracle import geometry as og
+    gen = torch.Generator().manual_seed(77)
+    B, H, W = 3, 20, 36
+    K = torch.tensor([[0.58 * W, 0, 0.5 * W], [0, 1.92 * H, 0.5 * H], [0, 0, 1]], dtype=torch.float64).repeat(B, 1, 1)
+    img = torch.randn(B, 3, H, W, generator=gen)
+    depth = (1 + 9 * torch.rand(B, H, W, generator=gen))
+    pose = 0.03 * torch.randn(B, 6, generator=gen)
+    coef = torch.randn(B, 3, H, W, generator=gen)
+    for inv in (False, True):
+        d0, p0 = depth.clone().requires_grad_(), pose.clone().requires_grad_()
+        (og.inverse_warp(img, d0, p0, K, inv) * coef).sum().backward()
+        d1, p1 = depth.to(DEV).requires_grad_(), pose.to(DEV).requires_grad_()
+        (inverse_warp(img.to(DEV), d1, p1, K.to(DEV), inv) * coef.to(DEV)).sum().backward()
+        assert rel_err(d1.grad, d0.grad) < 1e-3
+        assert rel_err(p1.grad, p0.grad) < 1e-3
+
+
+def test_transform_and_pose_matrices(golden):
+    from geometry.transform import Transform
+    from geometry import pose_geometry as pg
+    g = golden("loss_small.npz")
+    K, p, Dt = T(g["K"]), T(g["poses"]), T(g["depth_t"])
+    tr = Transform()
+    Xc = tr.reconstruct(Dt, K)
+    assert rel_err(Xc, g["cam_points"]) < 1e-6
+    Tcw = pg.transformation_from_parameters(p[:, 0, :3].unsqueeze(1), p[:, 0, 3:].unsqueeze(1))
+    assert rel_err(Tcw, g["Tcw0"]) < 1e-6
+    assert rel_err(pg.invert_pose(Tcw), g["Tcw0_inv"]) < 1e-6
+    assert rel_err(pg.transformation_from_parameters(p[:, 0, :3].unsqueeze(1), p[:, 0, 3:].unsqueeze(1), invert=True), g["Tcw0_inv"]) < 1e-6
+    assert rel_err(tr.project(Xc, K, Tcw), g["grid0"]) < 1e-5
+    R = pg.rot_from_axisangle(p[:, 0, :3].unsqueeze(1))
+    assert rel_err(R[:, :3, :3], g["Tcw0"][:, :3, :3]) < 1e-6 and float(R[:, :3, 3].abs().max()) == 0.0
+    Tm = pg.get_translation_matrix(p[:, 0, 3:].unsqueeze(1))
+    assert rel_err(Tm[:, :3, 3], g["Tcw0"][:, :3, 3]) < 1e-6
+    assert rel_err(Tm[:, :3, :3], np.tile(np.eye(3, dtype=np.float32), (4, 1, 1))) < 1e-6
+
+
+def test_disp_to_depth_and_smooth(golden):
+    from geometry.pose_geometry import disp_to_depth
+    from losses import Losses
+    g = golden("smooth.npz")
+    d0 = T(g["disp0"]).requires_grad_()
+    d1 = T(g["disp1"]).requires_grad_()
+    depth = disp_to_depth([[d0, d1]])[0]
+    assert rel_err(depth[0], g["depth0"]) < 1e-6
+    loss = Losses().smooth_loss(depth)
+    assert abs(float(loss) - float(g["loss"])) < 2e-6 * abs(float(g["loss"]))
+    (2.5 * loss).backward()
+    grad_close(d0.grad, 2.5 * g["g_disp0"])
+    grad_close(d1.grad, 2.5 * g["g_disp1"])
+
+
+def test_ssim(golden):
+    from losses import SSIM
+    g = golden("ssim.npz")
+    x, y = T(g["x"]), T(g["y"])
+    assert rel_err(SSIM().standard_loss(x, y), g["ssim"]) < 1e-4
+    assert float(SSIM().standard_loss(x, x).max()) < 1e-6
+    torch.manual_seed(1)
+    x3, y3 = torch.rand(4, 3, 64, 128), torch.rand(4, 3, 64, 128)
+    s3 = SSIM().standard_loss(x3.to(DEV), y3.to(DEV))
+    assert np.allclose([float(s3.mean()), float(s3.min()), float(s3.max())], g["ka3"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,W", [(12, 192, 640), (2, 64, 128), (5, 37, 53)])
+def test_losses_vs_oracle_at_size(B, H, W):
+    """BASELINE config sizes (and a ragged one): loss scalars + gradients against the CPU oracle."""
+    from losses import Losses
+    from oracle import losses as ol
+    from oracle.step import synthetic_batch
+    s = synthetic_batch(B, H, W, seed=99)
+    gen = torch.Generator().manual_seed(100)
+    disp_t = torch.rand(B, 1, H, W, generator=gen)
+    disp_r = torch.rand(B, 1, H, W, generator=gen)
+    poses = 0.01 * torch.randn(B, 2, 6, generator=gen)
+    a, b, c = disp_t.clone().requires_grad_(), disp_r.clone().requires_grad_(), poses.clone().requires_grad_()
+    want = ol.losses_forward(s["tgt"], s["ref_imgs"], [[a], [b]], c, s["intrinsics"])
+    sum(want).backward()
+    x, y, z = disp_t.to(DEV).requires_grad_(), disp_r.to(DEV).requires_grad_(), poses.to(DEV).requires_grad_()
+    got = Losses().forward(s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], [[x], [y]], z, s["intrinsics"].to(DEV), None)
+    assert abs(float(got[0]) - float(want[0])) < 1e-5 * abs(float(want[0]))
+    assert abs(float(got[1]) - float(want[1])) < 1e-5 * abs(float(want[1]))
+    sum(got).backward()
+    grad_close(x.grad, a.grad)
+    grad_close(y.grad, b.grad)
+    assert rel_err(z.grad, c.grad) < 1e-3

@@ -1,0 +1,259 @@
+// Per-pixel / per-sample arithmetic of the inverse-warp + photometric stage, shared by the HIP kernels
+// (warp_loss.hip) and by the host-compiled index/math check used in tests/hostcheck (never by the product).
+//
+// Follows, operation for operation in fp32 where the reference is fp32:
+//   geometry/transform.py:74-105   reconstruct   Xc = (K^-1 [x y 1]^T) * D
+//   geometry/transform.py:114-150  project       P = (K4 @ Tcw)[:3];  pix = P [Xc;1];  /(z + 1e-5);  x/(W-1), y/(H-1), (.-0.5)*2
+//   geometry/pose_geometry.py:110-199  Rodrigues (+1e-7), T = Trans @ Rot, rigid inverse
+//   geometry/pose_geometry.py:227  F.grid_sample(bilinear, zeros, align_corners=True)  (+ its backward w.r.t. the grid)
+//   geometry/pose_geometry.py:81-82  D = 1 / (10 * disp + 0.01)
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define MCAV_HD __host__ __device__ __forceinline__
+#else
+#define MCAV_HD inline
+#endif
+
+namespace mcav {
+
+// Per (sample, warp) constants, produced once per launch by pose_prepare().
+struct WarpConst {
+    float P[12];     // rows of (K4 @ Tcw)[:3, :4]
+};
+struct SampleConst {
+    float Kinv[9];   // float(K^-1), K inverted in fp64 as torch does for an fp64 K
+    WarpConst w[3];
+};
+
+MCAV_HD void invert3x3(const double* K, double* Ki) {
+    const double a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+    const double A = e * i - f * h, Bc = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * Bc + c * C;
+    const double r = 1.0 / det;
+    Ki[0] = A * r;  Ki[1] = -(b * i - c * h) * r;  Ki[2] = (b * f - c * e) * r;
+    Ki[3] = Bc * r; Ki[4] = (a * i - c * g) * r;   Ki[5] = -(a * f - c * d) * r;
+    Ki[6] = C * r;  Ki[7] = -(a * h - b * g) * r;  Ki[8] = (a * e - b * d) * r;
+}
+
+// axis-angle v[3] -> R[9] (row-major), fp32, same expression tree as the reference.
+MCAV_HD void rodrigues(const float* v, float* R) {
+    const float angle = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float inv = 1.0f / (angle + 1e-7f);
+    const float x = v[0] * inv, y = v[1] * inv, z = v[2] * inv;
+    const float ca = cosf(angle), sa = sinf(angle), C = 1.0f - ca;
+    const float xs = x * sa, ys = y * sa, zs = z * sa;
+    const float xC = x * C, yC = y * C, zC = z * C;
+    const float xyC = x * yC, yzC = y * zC, zxC = z * xC;
+    R[0] = x * xC + ca; R[1] = xyC - zs;    R[2] = zxC + ys;
+    R[3] = xyC + zs;    R[4] = y * yC + ca; R[5] = yzC - xs;
+    R[6] = zxC - ys;    R[7] = yzC + xs;    R[8] = z * zC + ca;
+}
+
+// pose[6] = (axis-angle, translation) -> 3x4 [R|t] of Tcw (optionally the rigid inverse).
+MCAV_HD void pose_to_Rt(const float* pose, bool invert, float* R, float* t) {
+    float R0[9];
+    rodrigues(pose, R0);
+    if (!invert) {
+        for (int i = 0; i < 9; ++i) R[i] = R0[i];
+        t[0] = pose[3]; t[1] = pose[4]; t[2] = pose[5];
+    } else {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) R[i * 3 + j] = R0[j * 3 + i];
+        for (int i = 0; i < 3; ++i)
+            t[i] = (-1.0f * R[i * 3 + 0]) * pose[3] + (-1.0f * R[i * 3 + 1]) * pose[4] + (-1.0f * R[i * 3 + 2]) * pose[5];
+    }
+}
+
+// P = K[3x3] @ [R|t]  (the first three rows of K4 @ Tcw).
+MCAV_HD void make_P(const float* K, const float* R, const float* t, float* P) {
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+            P[i * 4 + j] = K[i * 3 + 0] * R[0 * 3 + j] + K[i * 3 + 1] * R[1 * 3 + j] + K[i * 3 + 2] * R[2 * 3 + j];
+        P[i * 4 + 3] = K[i * 3 + 0] * t[0] + K[i * 3 + 1] * t[1] + K[i * 3 + 2] * t[2];
+    }
+}
+
+struct Ray { float r0, r1, r2; };
+
+MCAV_HD Ray pixel_ray(const float* Kinv, float x, float y) {
+    Ray r;
+    r.r0 = Kinv[0] * x + Kinv[1] * y + Kinv[2];
+    r.r1 = Kinv[3] * x + Kinv[4] * y + Kinv[5];
+    r.r2 = Kinv[6] * x + Kinv[7] * y + Kinv[8];
+    return r;
+}
+
+// Everything one warp needs at one target pixel.
+struct Tap {
+    float ix, iy;          // un-normalised sampling position in source pixels
+    float pix_x, pix_y;    // projected pixel coordinates (before normalisation)
+    float zi;              // 1 / (z + 1e-5)
+    float X0, X1, X2;      // camera point
+    int x0, y0;            // floor
+    float wx1, wx0, wy1, wy0;   // (ix - x0), (x1 - ix), (iy - y0), (y1 - iy)
+    bool in00, in01, in10, in11;  // tap (y0,x0) (y0,x1) (y1,x0) (y1,x1) inside the image
+};
+
+MCAV_HD Tap project_pixel(const float* P, const Ray& r, float D, int H, int W) {
+    Tap t;
+    t.X0 = r.r0 * D; t.X1 = r.r1 * D; t.X2 = r.r2 * D;
+    const float c0 = P[0] * t.X0 + P[1] * t.X1 + P[2] * t.X2 + P[3];
+    const float c1 = P[4] * t.X0 + P[5] * t.X1 + P[6] * t.X2 + P[7];
+    const float c2 = P[8] * t.X0 + P[9] * t.X1 + P[10] * t.X2 + P[11];
+    const float z = c2 + 1e-5f;
+    t.zi = 1.0f / z;
+    t.pix_x = c0 / z;
+    t.pix_y = c1 / z;
+    const float gx = (t.pix_x / (float)(W - 1) - 0.5f) * 2.0f;
+    const float gy = (t.pix_y / (float)(H - 1) - 0.5f) * 2.0f;
+    t.ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    t.iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    // clamp to a range where float->int is defined; anything outside [-1, size] has no in-bounds tap anyway
+    // (NaN compares false everywhere and ends up with all taps out of bounds)
+    float cx = t.ix, cy = t.iy;
+    if (!(cx > -2.0f)) cx = -2.0f;
+    if (!(cx < (float)W + 1.0f)) cx = (float)W + 1.0f;
+    if (!(cy > -2.0f)) cy = -2.0f;
+    if (!(cy < (float)H + 1.0f)) cy = (float)H + 1.0f;
+    const float fx = floorf(cx), fy = floorf(cy);
+    t.x0 = (int)fx; t.y0 = (int)fy;
+    const bool finite = (t.ix == t.ix) && (t.iy == t.iy) && (cx == t.ix) && (cy == t.iy);
+    t.wx1 = t.ix - fx;            // weight of the east column
+    t.wx0 = (fx + 1.0f) - t.ix;   // weight of the west column
+    t.wy1 = t.iy - fy;
+    t.wy0 = (fy + 1.0f) - t.iy;
+    const bool xin0 = finite && t.x0 >= 0 && t.x0 < W, xin1 = finite && t.x0 + 1 >= 0 && t.x0 + 1 < W;
+    const bool yin0 = finite && t.y0 >= 0 && t.y0 < H, yin1 = finite && t.y0 + 1 >= 0 && t.y0 + 1 < H;
+    t.in00 = yin0 && xin0; t.in01 = yin0 && xin1; t.in10 = yin1 && xin0; t.in11 = yin1 && xin1;
+    return t;
+}
+
+// Bilinear value and its derivative w.r.t. (ix, iy) for one channel plane.
+struct Sample { float v, dvdx, dvdy; };
+
+MCAV_HD Sample bilinear(const float* plane, int W, const Tap& t) {
+    const float nw = t.in00 ? plane[t.y0 * W + t.x0] : 0.0f;
+    const float ne = t.in01 ? plane[t.y0 * W + t.x0 + 1] : 0.0f;
+    const float sw = t.in10 ? plane[(t.y0 + 1) * W + t.x0] : 0.0f;
+    const float se = t.in11 ? plane[(t.y0 + 1) * W + t.x0 + 1] : 0.0f;
+    Sample s;
+    s.v = nw * (t.wx0 * t.wy0) + ne * (t.wx1 * t.wy0) + sw * (t.wx0 * t.wy1) + se * (t.wx1 * t.wy1);
+    s.dvdx = -nw * t.wy0 + ne * t.wy0 - sw * t.wy1 + se * t.wy1;
+    s.dvdy = -nw * t.wx0 - ne * t.wx1 + sw * t.wx0 + se * t.wx1;
+    return s;
+}
+
+// Chain d(loss)/d(ix, iy) back to depth and to the 12 entries of P.
+// gix/giy: d loss / d ix, iy.  Returns d loss / d D and accumulates dP (12 floats).
+MCAV_HD float backproject_grad(const float* P, const Ray& r, const Tap& t, float gix, float giy, int H, int W, float* dP) {
+    // ix = ((g+1)/2)(W-1), g = (pix/(W-1) - .5)*2  ->  d pix = gix * ((W-1)/2) * (2/(W-1))
+    const float dpx = (gix * ((float)(W - 1) / 2.0f)) * (2.0f / (float)(W - 1));
+    const float dpy = (giy * ((float)(H - 1) / 2.0f)) * (2.0f / (float)(H - 1));
+    const float dc0 = dpx * t.zi;
+    const float dc1 = dpy * t.zi;
+    const float dc2 = -(dpx * t.pix_x + dpy * t.pix_y) * t.zi;
+    dP[0] += dc0 * t.X0; dP[1] += dc0 * t.X1; dP[2] += dc0 * t.X2;  dP[3] += dc0;
+    dP[4] += dc1 * t.X0; dP[5] += dc1 * t.X1; dP[6] += dc1 * t.X2;  dP[7] += dc1;
+    dP[8] += dc2 * t.X0; dP[9] += dc2 * t.X1; dP[10] += dc2 * t.X2; dP[11] += dc2;
+    const float q0 = P[0] * r.r0 + P[1] * r.r1 + P[2] * r.r2;
+    const float q1 = P[4] * r.r0 + P[5] * r.r1 + P[6] * r.r2;
+    const float q2 = P[8] * r.r0 + P[9] * r.r1 + P[10] * r.r2;
+    return dc0 * q0 + dc1 * q1 + dc2 * q2;
+}
+
+MCAV_HD float sgn(float v) { return (float)((v > 0.0f) - (v < 0.0f)); }
+
+// Second-order smoothness (losses.py:242-260) at pixel (x, y): DD(dy, dx) reads the depth at (y+dy, x+dx).
+// ls += this pixel's share of the loss (each term is counted once, by the pixel at its origin);
+// gs += d loss / d D[y][x] (gathered from every term D[y][x] takes part in).
+// cxx/cyy/cxy: weight / element count of the dx2, dy2 and (dxdy + dydx) means.
+template <class F>
+MCAV_HD void smooth_terms(F DD, int x, int y, int H, int W, float cxx, float cyy, float cxy, float& ls, float& gs) {
+    // second difference along x: t(x') = D[x'+2] - 2 D[x'+1] + D[x'], x' in [0, W-3]
+    if (x <= W - 3) { const float t = DD(0, 2) - 2.f * DD(0, 1) + DD(0, 0); ls += fabsf(t) * cxx; gs += sgn(t) * cxx; }
+    if (x >= 1 && x <= W - 2) { const float t = DD(0, 1) - 2.f * DD(0, 0) + DD(0, -1); gs -= 2.f * sgn(t) * cxx; }
+    if (x >= 2) { const float t = DD(0, 0) - 2.f * DD(0, -1) + DD(0, -2); gs += sgn(t) * cxx; }
+    // second difference along y
+    if (y <= H - 3) { const float t = DD(2, 0) - 2.f * DD(1, 0) + DD(0, 0); ls += fabsf(t) * cyy; gs += sgn(t) * cyy; }
+    if (y >= 1 && y <= H - 2) { const float t = DD(1, 0) - 2.f * DD(0, 0) + DD(-1, 0); gs -= 2.f * sgn(t) * cyy; }
+    if (y >= 2) { const float t = DD(0, 0) - 2.f * DD(-1, 0) + DD(-2, 0); gs += sgn(t) * cyy; }
+    // mixed difference u(y',x') = (D[y'+1,x'+1] - D[y'+1,x']) - (D[y',x'+1] - D[y',x']); dxdy and dydx are the same field
+    if (y <= H - 2 && x <= W - 2) { const float u = (DD(1, 1) - DD(1, 0)) - (DD(0, 1) - DD(0, 0)); ls += fabsf(u) * cxy; gs += sgn(u) * cxy; }
+    if (y <= H - 2 && x >= 1) { const float u = (DD(1, 0) - DD(1, -1)) - (DD(0, 0) - DD(0, -1)); gs -= sgn(u) * cxy; }
+    if (y >= 1 && x <= W - 2) { const float u = (DD(0, 1) - DD(0, 0)) - (DD(-1, 1) - DD(-1, 0)); gs -= sgn(u) * cxy; }
+    if (y >= 1 && x >= 1) { const float u = (DD(0, 0) - DD(0, -1)) - (DD(-1, 0) - DD(-1, -1)); gs += sgn(u) * cxy; }
+}
+
+// One warp at one pixel: photometric L1 over 3 channel planes + gradient back to depth and P.
+// src: 3 planes of the source image (stride `plane`), tv: the 3 target values.
+// lw: weight of |res| in the loss; gw: weight of sign(res) in the gradient (= upstream * lw).
+MCAV_HD void warp_pixel(const float* src, size_t plane, const float* tv, const float* P, const Ray& r, float D, int H, int W,
+                        float lw, float gw, float& loss, float& dD, float* dP) {
+    const Tap t = project_pixel(P, r, D, H, W);
+    float gix = 0.f, giy = 0.f;
+    for (int c = 0; c < 3; ++c) {
+        const Sample s = bilinear(src + c * plane, W, t);
+        const float res = s.v - tv[c];
+        loss += fabsf(res) * lw;
+        const float sg = sgn(res) * gw;
+        gix += sg * s.dvdx;
+        giy += sg * s.dvdy;
+    }
+    dD += backproject_grad(P, r, t, gix, giy, H, W, dP);
+}
+
+// d loss / dP (3x4, summed over pixels, fp64) -> d loss / d pose[6], through K, the optional rigid inverse,
+// T = Trans @ Rot and Rodrigues with the +1e-7 guard.  All in fp64.
+MCAV_HD void pose_grad_from_dP(const double* dP, const float* Kf, const float* pose, bool invert, double* dpose) {
+    // dM = K^T dP  (M = [R|t] actually used, 3x4)
+    double dM[12];
+    for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < 4; ++j)
+            dM[k * 4 + j] = (double)Kf[0 * 3 + k] * dP[0 * 4 + j] + (double)Kf[1 * 3 + k] * dP[1 * 4 + j] + (double)Kf[2 * 3 + k] * dP[2 * 4 + j];
+    const double vx = pose[0], vy = pose[1], vz = pose[2];
+    const double tx = pose[3], ty = pose[4], tz = pose[5];
+    const double angle = sqrt(vx * vx + vy * vy + vz * vz);
+    const double inv = 1.0 / (angle + (double)1e-7f);
+    const double x = vx * inv, y = vy * inv, z = vz * inv;
+    const double ca = cos(angle), sa = sin(angle), C = 1.0 - ca;
+    double R0[9] = {x * x * C + ca, x * y * C - z * sa, z * x * C + y * sa,
+                    x * y * C + z * sa, y * y * C + ca, y * z * C - x * sa,
+                    z * x * C - y * sa, y * z * C + x * sa, z * z * C + ca};
+    double dR[9], dt[3];
+    if (!invert) {
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) dR[i * 3 + j] = dM[i * 4 + j];
+            dt[i] = dM[i * 4 + 3];
+        }
+    } else {
+        // M[:, :3] = R0^T ; M[:, 3]_i = -sum_a R0[a][i] t_a
+        const double t0[3] = {tx, ty, tz};
+        for (int a = 0; a < 3; ++a) {
+            double acc = 0.0;
+            for (int i = 0; i < 3; ++i) {
+                dR[a * 3 + i] = dM[i * 4 + a] - dM[i * 4 + 3] * t0[a];
+                acc -= R0[a * 3 + i] * dM[i * 4 + 3];
+            }
+            dt[a] = acc;
+        }
+    }
+    const double dx = dR[0] * 2 * x * C + (dR[1] + dR[3]) * y * C + (dR[2] + dR[6]) * z * C + (dR[7] - dR[5]) * sa;
+    const double dy = (dR[1] + dR[3]) * x * C + dR[4] * 2 * y * C + (dR[5] + dR[7]) * z * C + (dR[2] - dR[6]) * sa;
+    const double dz = (dR[2] + dR[6]) * x * C + (dR[5] + dR[7]) * y * C + dR[8] * 2 * z * C + (dR[3] - dR[1]) * sa;
+    const double dC = dR[0] * x * x + (dR[1] + dR[3]) * x * y + (dR[2] + dR[6]) * z * x + dR[4] * y * y + (dR[5] + dR[7]) * y * z + dR[8] * z * z;
+    const double dca = dR[0] + dR[4] + dR[8];
+    const double dsa = (dR[3] - dR[1]) * z + (dR[2] - dR[6]) * y + (dR[7] - dR[5]) * x;
+    double dangle = -sa * dca + ca * dsa + sa * dC;
+    // axis_i = v_i * inv ; inv = 1/(angle+eps)
+    const double daxis_dot_v = dx * vx + dy * vy + dz * vz;
+    dangle -= daxis_dot_v * inv * inv;
+    const double s = angle > 0.0 ? dangle / angle : 0.0;   // d|v|/dv = v/|v| (0 at v = 0, as torch.norm's backward)
+    dpose[0] = dx * inv + s * vx;
+    dpose[1] = dy * inv + s * vy;
+    dpose[2] = dz * inv + s * vz;
+    dpose[3] = dt[0]; dpose[4] = dt[1]; dpose[5] = dt[2];
+}
+
+}  // namespace mcav

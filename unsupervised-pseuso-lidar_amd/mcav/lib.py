@@ -1,0 +1,103 @@
+"""ctypes binding of libmcav_depth.so (the drop-in boundary, include/mcav_depth.h)."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcav_depth.so")
+_LIB = None
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_u = ctypes.c_uint
+c_f = ctypes.c_float
+c_sz = ctypes.c_size_t
+
+WL_K_F64, WL_SKIP_IF_UNIT, WL_NO_SMOOTH, WL_INPUT_DEPTH = 1, 2, 4, 8
+
+
+class MCAVError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "MCAV_E_INVALID (bad argument)", -2: "MCAV_E_WORKSPACE (workspace too small)", -3: "MCAV_E_LAUNCH (HIP launch error)"}
+
+_SIGNATURES = {
+    "mcav_abi_version": (c_i, []),
+    "mcav_warp_loss_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "mcav_warp_loss_fwd_bwd": (c_i, [c_p] * 7 + [c_i, c_i, c_i, c_u, c_p, c_p] + [c_p] * 4 + [c_p, c_sz, c_p]),
+    "mcav_inverse_warp_fwd": (c_i, [c_p] * 4 + [c_i, c_i, c_i, c_i, c_u, c_p, c_p, c_sz, c_p]),
+    "mcav_inverse_warp_bwd": (c_i, [c_p] * 5 + [c_i, c_i, c_i, c_i, c_u, c_p, c_p, c_p, c_sz, c_p]),
+    "mcav_reconstruct": (c_i, [c_p, c_p, c_i, c_i, c_i, c_u, c_p, c_p, c_sz, c_p]),
+    "mcav_project": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_u, c_p, c_p]),
+    "mcav_disp_to_depth": (c_i, [c_p, c_p, c_sz, c_p]),
+    "mcav_disp_to_depth_bwd": (c_i, [c_p, c_p, c_p, c_sz, c_p]),
+    "mcav_ssim_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p]),
+    "mcav_smooth_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "mcav_smooth_loss_fwd_bwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_i, c_p, c_sz, c_p]),
+}
+
+
+def register(signatures):
+    """Let other host modules (conv, norm, optimiser ...) declare the entry points they bind."""
+    _SIGNATURES.update(signatures)
+    if _LIB is not None:
+        _declare(_LIB, signatures)
+
+
+def _declare(handle, signatures):
+    for name, (res, args) in signatures.items():
+        fn = getattr(handle, name)      # AttributeError here = header and library out of sync
+        fn.restype = res
+        fn.argtypes = args
+
+
+def lib():
+    """The loaded library.  Fails loudly when it has not been built: the product has no other path."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise MCAVError("libmcav_depth.so is missing (%s). Build it: python -c 'import __graft_entry__ as g; g.build()' "
+                            "or `make -C unsupervised-pseuso-lidar_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        _declare(handle, _SIGNATURES)
+        _LIB = handle
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MCAVError("%s failed: %s" % (what, _ERR.get(rc, rc)))
+
+
+def dev(t, name="tensor", dtype=torch.float32):
+    """Validate a tensor handed to the C ABI: on the GPU, contiguous, expected dtype."""
+    if not t.is_cuda:
+        raise MCAVError("%s must live on the GPU: the MI355X path has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise MCAVError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise MCAVError("%s must be contiguous" % name)
+    return t
+
+
+def ptr(t):
+    return c_p(t.data_ptr()) if t is not None else c_p(0)
+
+
+def stream():
+    return c_p(torch.cuda.current_stream().cuda_stream)
+
+
+_WS = {}
+
+
+def workspace(nbytes, device, key="default"):
+    """A cached byte workspace per (device, key); grown on demand, reused across calls on one stream."""
+    k = (str(device), key)
+    buf = _WS.get(k)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+        _WS[k] = buf
+    return buf
