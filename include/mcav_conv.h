@@ -1,0 +1,144 @@
+/* mcav_conv.h -- C ABI of the network kernels of libmcav_depth.so (gfx950): implicit-GEMM convolution on the
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), its data- and weight-gradients, BatchNorm, pooling, layout
+ * and the optimiser.  These replace the torch.nn / torchvision ops the reference's networks are made of:
+ *   models/depth/resnet_dispnet.py:12-107 (ResnetEncoder via torchvision resnet, DepthDecoder, DispResNet)
+ *   models/depth/layers.py:22-58 (Conv3x3 reflection pad + conv, ConvBlock ELU, nearest upsample)
+ *   models/pose/pose_net.py:31-77, models/pose/pose_fc.py:21-84, models/depth/disp_net.py:51-141
+ *   trainer.py:71-76,261-266 (Adam, zero_grad, step)
+ *
+ * Activations are NHWC fp32 ("pixel-major"): element (b, y, x, c) at ((b*H + y)*W + x)*C + c.
+ * Conv weights are consumed in the packed form [Np][kh*kw][Kp] (output channel, tap, input channel; Np and Kp
+ * are the channel counts rounded up to 16, zero filled) produced by mcav_pack_weights from the reference's
+ * OIHW parameters; weight gradients are written back in OIHW.
+ * All pointers are device memory; `stream` is a hipStream_t; return codes as in mcav_depth.h.
+ */
+#ifndef MCAV_CONV_H
+#define MCAV_CONV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* gather modes: how a destination pixel d and a filter tap k address the source */
+#define MCAV_G_DIRECT 0      /* s = d*stride + sign*k + offset per axis; zero or reflection padding */
+#define MCAV_G_SMALLC 1      /* as DIRECT, zero padding, source has exactly 4 channels (image stem) */
+#define MCAV_G_ADJ_REFLECT 2 /* adjoint of a 3x3 stride-1 reflection-padded conv (border pixels sum 2 sources per axis) */
+#define MCAV_G_ADJ_STRIDE2 3 /* adjoint of a stride-2 zero-padded conv: s = (d + pad - k)/2 when even; parity-class tiles */
+
+#define MCAV_PAD_ZERO 0
+#define MCAV_PAD_REFLECT 1
+
+#define MCAV_ACT_NONE 0
+#define MCAV_ACT_RELU 1
+#define MCAV_ACT_ELU 2
+#define MCAV_ACT_SIGMOID 3
+
+/* One gather-GEMM launch: y[pix, n] = epilogue( sum_{tap, c} src(pix, tap)[c] * w[n][tap][c] ).
+ * Used for the forward convolution and (with the adjoint gather modes / transposed packed weights) for dgrad. */
+typedef struct mcav_igemm_desc {
+    /* source: logical [B, Hs, Ws, C1 + C2]; channels [0, C1) come from x1, [C1, C1+C2) from x2 (fused concat) */
+    const float* x1;
+    const float* x2;
+    int B, Hs, Ws, C1, C2;
+    int up1;          /* 1: x1 is stored at (Hs/2, Ws/2) and nearest-upsampled x2 on the fly (decoder) */
+    /* packed filter [Np][kh*kw][Kp], Kp >= C1 + C2 */
+    const float* w;
+    int kh, kw, Np, Kp;
+    int mode, stride, sign, offset, pad_mode;
+    /* destination: logical [B, Hd, Wd, *]; this launch computes filter rows [n_begin, n_begin + n_count) and writes
+     * them to channels [y_choff, y_choff + n_count) of y, whose pixel stride is Cd floats */
+    float* y;
+    int Hd, Wd, Cd, n_begin, n_count, y_choff;
+    /* epilogue, in this order: + bias[n]; activation; * act'(dact_aux) ; + addend; 2x2 sum pooling */
+    const float* bias;
+    int act;
+    const float* dact_aux;  /* same layout as y; dact = MCAV_ACT_* whose derivative (as a function of the OUTPUT) multiplies */
+    int dact;
+    const float* addend;    /* same layout as y */
+    int pool;               /* 1: destination pixels are visited in 2x2 blocks and summed: y is [B, Hd/2, Wd/2, Cd] */
+    float* stats;           /* NULL or [mtiles][2][n_count]: per-tile column sums of y and y^2 (BatchNorm batch statistics) */
+    int tile;               /* 0 = choose automatically; else a tile-config id (see mcav_igemm_tile_info) */
+} mcav_igemm_desc;
+
+/* number of M-tiles (rows of `stats`) the launch will use with its chosen tile config */
+int mcav_igemm_mtiles(const mcav_igemm_desc* d);
+int mcav_igemm(const mcav_igemm_desc* d, void* stream);
+
+/* Weight gradient: dw[n][tap][c] = sum_pix dy[pix, n] * src(pix, tap)[c], reduced over pixel splits and written
+ * (accumulated if accumulate != 0) in OIHW [Cout][Cin][kh][kw] to dw_oihw.  The source is gathered exactly as in
+ * the forward launch (modes DIRECT / SMALLC). */
+typedef struct mcav_wgrad_desc {
+    const float* x1;
+    const float* x2;
+    int B, Hs, Ws, C1, C2, up1;
+    int kh, kw, Kp;
+    int mode, stride, sign, offset, pad_mode;
+    const float* dy;        /* [B, Hd, Wd, Cdy], channels [dy_choff, dy_choff + Cout) are used */
+    int Hd, Wd, Cdy, dy_choff;
+    int Cout, Cin;          /* true channel counts of the OIHW gradient */
+    float* dw_oihw;
+    int accumulate;
+    float* dbias;           /* NULL or [Cout]: sum over pixels of dy (accumulated if accumulate != 0) */
+    int tile;
+} mcav_wgrad_desc;
+
+size_t mcav_wgrad_workspace_bytes(const mcav_wgrad_desc* d);
+int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* OIHW [Cout][Cin][kh][kw] -> packed forward filter [Np][taps][Kp] (transposed = 0)
+ *                          or packed data-gradient filter [Kp'][taps][Np'] with in/out swapped (transposed = 1). */
+int mcav_pack_weights(const float* w_oihw, int Cout, int Cin, int kh, int kw, int transposed, float* packed, int Np, int Kp,
+                      void* stream);
+
+/* NCHW image [B, C, H, W] -> NHWC [B, H, W, Cp] at channel offset choff (other channels untouched; zero the buffer first). */
+int mcav_nchw_to_nhwc(const float* src, int B, int C, int H, int W, float* dst, int Cp, int choff, void* stream);
+int mcav_nhwc_to_nchw(const float* src, int B, int C, int H, int W, int Cp, int choff, float* dst, void* stream);
+
+/* BatchNorm2d, training mode (torchvision BasicBlock/Bottleneck; batch statistics, eps, momentum as nn.BatchNorm2d).
+ * finalize: reduce the per-tile column sums written by mcav_igemm into mean / biased variance, produce
+ *   scale = gamma * rsqrt(var + eps), shift = beta - mean * scale, save mean and invstd for backward, and update
+ *   running_mean / running_var (unbiased) with `momentum`.  count = pixels per channel. */
+int mcav_bn_finalize(const float* stats, int mtiles, int C, double count, const float* gamma, const float* beta, float eps,
+                     float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* save_mean,
+                     float* save_invstd, void* stream);
+/* eval mode: scale/shift from the running statistics */
+int mcav_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
+                        float* scale, float* shift, void* stream);
+/* y = act(x * scale[c] + shift[c] (+ residual)); n_pix pixels of C channels; act = NONE or RELU */
+int mcav_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, int act, size_t n_pix, int C, float* y,
+                  void* stream);
+/* backward, pass 1: dz = dy * (y > 0 if relu); per-channel sums of dz and dz * xhat -> dgamma, dbeta (accumulated if accumulate) */
+size_t mcav_bn_bwd_workspace_bytes(size_t n_pix, int C);
+int mcav_bn_bwd_reduce(const float* dy, const float* y_act, const float* x, const float* save_mean, const float* save_invstd, int relu,
+                       size_t n_pix, int C, float* dgamma, float* dbeta, int accumulate, float* sums /* [2][C] out */,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* backward, pass 2: dx = gamma * invstd * (dz - sum_dz / N - xhat * sum_dz_xhat / N); optionally also stores dz (the
+ * gradient flowing to the residual branch) to dres (added into it if dres_accumulate) */
+int mcav_bn_bwd_apply(const float* dy, const float* y_act, const float* x, const float* gamma, const float* save_mean,
+                      const float* save_invstd, const float* sums, int relu, size_t n_pix, int C, float* dx, float* dres,
+                      int dres_accumulate, void* stream);
+
+/* MaxPool2d(3, stride 2, pad 1) on NHWC; idx stores the winning tap (0..8, first maximum in row-major window order). */
+int mcav_maxpool3s2_fwd(const float* x, int B, int H, int W, int C, float* y, uint8_t* idx, void* stream);
+/* dx (+)= scatter of dy through idx, gathered per input pixel; then multiplied by (xact > 0) when relu_mask != NULL... */
+int mcav_maxpool3s2_bwd(const float* dy, const uint8_t* idx, int B, int H, int W, int C, float* dx, int accumulate, void* stream);
+
+/* elementwise helpers on flat buffers */
+int mcav_act_bwd(const float* dy, const float* y, int act, size_t n, float* dx, int accumulate, void* stream);
+int mcav_add(const float* a, const float* b, size_t n, float* out, void* stream);
+/* out[b, c] = scale * mean over pixels of x[b, pix, c]  (PoseNet head: mean(3).mean(2) * 0.06), and its backward */
+int mcav_spatial_mean(const float* x, int B, int n_pix, int C, float scale, float* out, void* stream);
+int mcav_spatial_mean_bwd(const float* dout, int B, int n_pix, int C, float scale, float* dx, void* stream);
+
+/* Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad) over one flat arena.
+ * step is the 1-based step count AFTER this update.  grad_scale multiplies the gradient first (1/world_size for DP). */
+int mcav_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                   float eps, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCAV_CONV_H */

@@ -1,0 +1,212 @@
+"""GPU: the implicit-GEMM conv kernels (forward, dgrad, wgrad) and the HBM-bound NN kernels against torch CPU ops."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def nhwc(t, cp=None):
+    """NCHW cpu tensor -> NHWC cuda tensor (optionally zero-padded to cp channels)."""
+    t = t.permute(0, 2, 3, 1).contiguous()
+    if cp is not None and cp != t.shape[3]:
+        t = torch.cat([t, torch.zeros(*t.shape[:3], cp - t.shape[3])], 3)
+    return t.contiguous().to(DEV)
+
+
+def nchw(t, c=None):
+    t = t.detach().cpu()
+    if c is not None:
+        t = t[..., :c]
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def ref_conv(x, w, b, stride, pad, pad_mode, act):
+    if pad_mode == 1 and pad > 0:
+        x = F.pad(x, (pad,) * 4, mode="reflect")
+        pad = 0
+    y = F.conv2d(x, w, b, stride=stride, padding=pad)
+    return {0: lambda v: v, 1: F.relu, 2: F.elu, 3: torch.sigmoid}[act](y)
+
+
+CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, pad_mode, act, tile
+    (2, 12, 20, 16, 16, 3, 1, 1, 1, 2, 0),      # decoder (0,1)-like, N=16 -> MFMA16 tiles
+    (2, 12, 20, 32, 32, 3, 1, 1, 1, 2, 0),      # N=32
+    (2, 12, 20, 64, 64, 3, 1, 1, 0, 0, 1),      # resnet 3x3, tile 128x64
+    (2, 12, 20, 64, 64, 3, 1, 1, 0, 0, 2),      # tile 64x64
+    (1, 10, 18, 64, 128, 3, 2, 1, 0, 0, 0),     # stride 2
+    (2, 9, 15, 64, 128, 1, 2, 0, 0, 0, 0),      # 1x1 stride-2 downsample, odd sizes
+    (2, 12, 20, 128, 128, 3, 1, 1, 0, 1, 5),    # tile 128x128
+    (2, 8, 12, 16, 1, 3, 1, 1, 1, 3, 0),        # dispconv: Cout = 1, sigmoid
+    (2, 16, 24, 9, 16, 7, 2, 3, 0, 1, 0),       # pose conv1: Cin = 9 padded to 16
+    (2, 7, 11, 16, 32, 5, 2, 2, 0, 1, 0),       # pose conv2, odd sizes
+    (3, 3, 10, 256, 256, 3, 2, 1, 0, 1, 0),     # pose conv6/7 geometry
+    (2, 6, 10, 96, 32, 3, 1, 1, 1, 2, 0),       # Cin = 96 (decoder (1,1))
+    (2, 6, 10, 32, 16, 3, 1, 1, 1, 2, 6),       # tile 64x16
+    (2, 6, 10, 32, 32, 3, 1, 1, 1, 2, 3),       # tile 256x32
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad(case):
+    from mcav import nn as N
+    B, H, W, Cin, Cout, k, stride, pad, pad_mode, act, tile = case
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    x = torch.randn(B, Cin, H, W, generator=g).requires_grad_()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5).requires_grad_()
+    b = (0.1 * torch.randn(Cout, generator=g)).requires_grad_()
+    pre = ref_conv(x, w, b, stride, pad, pad_mode, 0)
+    want = {0: lambda v: v, 1: F.relu, 2: F.elu, 3: torch.sigmoid}[act](pre)
+    dy = torch.randn(pre.shape, generator=g)
+    pre.backward(dy)
+
+    wp = torch.nn.Parameter(w.detach().to(DEV))
+    bp = torch.nn.Parameter(b.detach().to(DEV))
+    spec = N.ConvSpec(wp, bp, stride, pad, pad_mode)
+    xin = nhwc(x.detach(), N.up16(Cin) if Cin % 4 else None)
+    got = N.conv_fwd(spec, xin, act=act, tile=tile)
+    assert rel_err(nchw(got), want) < 2e-5
+    # dgrad (gradient at the pre-activation output), wgrad + bias grad
+    dyd = nhwc(dy)
+    dx = N.conv_dgrad(spec, dyd, (H, W), tile=tile)
+    assert rel_err(nchw(dx, Cin), x.grad) < 2e-5
+    N.conv_wgrad(spec, xin, dyd)
+    assert rel_err(wp.grad, w.grad) < 5e-5
+    assert rel_err(bp.grad, b.grad) < 5e-5
+    N.conv_wgrad(spec, xin, dyd)                     # accumulates
+    assert rel_err(wp.grad, 2 * w.grad) < 5e-5
+
+
+def test_conv_stats_and_epilogues():
+    from mcav import nn as N
+    g = torch.Generator().manual_seed(3)
+    B, H, W, Cin, Cout = 2, 10, 14, 64, 64
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    spec = N.ConvSpec(torch.nn.Parameter(w.to(DEV)), None, 1, 1, 0)
+    y, slab = N.conv_fwd(spec, nhwc(x), stats=True)
+    want = F.conv2d(x, w, None, padding=1)
+    assert rel_err(nchw(y), want) < 2e-5
+    s = slab.sum(0).cpu()
+    assert rel_err(s[0], want.sum((0, 2, 3))) < 1e-4
+    assert rel_err(s[1], (want ** 2).sum((0, 2, 3))) < 1e-4
+    # dgrad epilogue: * relu'(aux) + addend
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    aux = torch.randn(B, Cin, H, W, generator=g)
+    add = torch.randn(B, Cin, H, W, generator=g)
+    xr = x.clone().requires_grad_()
+    F.conv2d(xr, w, None, padding=1).backward(dy)
+    want_dx = xr.grad * (aux > 0).float() + add
+    got = N.conv_dgrad(spec, nhwc(dy), (H, W), dact_aux=nhwc(aux), dact=N.ACT_RELU, addend=nhwc(add))
+    assert rel_err(nchw(got), want_dx) < 2e-5
+
+
+def test_decoder_level_fused_upsample_concat():
+    """conv(cat(up2(a), skip)) with reflection padding: forward, wgrad, and the split/pooled dgrad."""
+    from mcav import nn as N
+    g = torch.Generator().manual_seed(4)
+    B, h, w_, C1, C2, Cout = 2, 5, 7, 32, 64, 32
+    a = torch.randn(B, C1, h, w_, generator=g).requires_grad_()
+    skip = torch.randn(B, C2, 2 * h, 2 * w_, generator=g).requires_grad_()
+    wt = (torch.randn(Cout, C1 + C2, 3, 3, generator=g) * 0.05).requires_grad_()
+    bs = (0.1 * torch.randn(Cout, generator=g)).requires_grad_()
+    xcat = torch.cat([F.interpolate(a, scale_factor=2, mode="nearest"), skip], 1)
+    pre = F.conv2d(F.pad(xcat, (1, 1, 1, 1), mode="reflect"), wt, bs)
+    want = F.elu(pre)
+    dy = torch.randn(pre.shape, generator=g)
+    pre.backward(dy)
+    wp, bp = torch.nn.Parameter(wt.detach().to(DEV)), torch.nn.Parameter(bs.detach().to(DEV))
+    spec = N.ConvSpec(wp, bp, 1, 1, 1)
+    got = N.conv_fwd(spec, nhwc(a.detach()), nhwc(skip.detach()), up1=True, act=N.ACT_ELU)
+    assert rel_err(nchw(got), want) < 2e-5
+    dyd = nhwc(dy)
+    N.conv_wgrad(spec, nhwc(a.detach()), dyd, x2=nhwc(skip.detach()), up1=True)
+    assert rel_err(wp.grad, wt.grad) < 5e-5 and rel_err(bp.grad, bs.grad) < 5e-5
+    da = N.conv_dgrad(spec, dyd, (2 * h, 2 * w_), n_begin=0, n_count=C1, pool=True)
+    assert rel_err(nchw(da), a.grad) < 2e-5
+    ds = N.conv_dgrad(spec, dyd, (2 * h, 2 * w_), n_begin=C1, n_count=C2)
+    assert rel_err(nchw(ds), skip.grad) < 2e-5
+
+
+def test_stem_smallc():
+    from mcav import nn as N
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 20, 28, generator=g)
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).requires_grad_()
+    y = F.conv2d(x, w, None, stride=2, padding=3)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    wp = torch.nn.Parameter(w.detach().to(DEV))
+    spec = N.ConvSpec(wp, None, 2, 3, 0, smallc=True)
+    x4 = N.nchw_to_nhwc(x.to(DEV), 4)
+    got = N.conv_fwd(spec, x4)
+    assert rel_err(nchw(got), y) < 2e-5
+    N.conv_wgrad(spec, x4, nhwc(dy))
+    assert rel_err(wp.grad, w.grad) < 5e-5
+
+
+def test_batchnorm_train_and_backward():
+    from mcav import nn as N
+    from mcav.holders import BNParams
+    g = torch.Generator().manual_seed(6)
+    B, C, H, W = 3, 64, 9, 13
+    x = (1.5 * torch.randn(B, C, H, W, generator=g) + 0.7).requires_grad_()
+    res = torch.randn(B, C, H, W, generator=g).requires_grad_()
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.1 * torch.randn(C, generator=g))
+        bn.bias.copy_(0.1 * torch.randn(C, generator=g))
+    out = F.relu(bn(x) + res)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy)
+    hb = BNParams(C).to(DEV)
+    with torch.no_grad():
+        hb.weight.copy_(bn.weight.detach())
+        hb.bias.copy_(bn.bias.detach())
+    # statistics slab as the conv epilogue would write it: one "tile" holding the sums
+    xd = nhwc(x.detach())
+    slab = torch.stack([xd.sum((0, 1, 2)), (xd * xd).sum((0, 1, 2))]).view(1, 2, C).contiguous()
+    st = N.bn_train_coeffs(hb, slab, B * H * W)
+    y = N.bn_apply(xd, st, True, nhwc(res.detach()))
+    assert rel_err(nchw(y), out) < 1e-5
+    assert rel_err(hb.running_mean, bn.running_mean) < 1e-5 and rel_err(hb.running_var, bn.running_var) < 1e-5
+    assert int(hb.num_batches_tracked) == 1
+    dx, dz = N.bn_backward(hb, st, nhwc(dy), y, xd, True, want_dres=True)
+    assert rel_err(nchw(dx), x.grad) < 1e-4
+    assert rel_err(nchw(dz), res.grad) < 1e-6
+    assert rel_err(hb.weight.grad, bn.weight.grad) < 1e-4 and rel_err(hb.bias.grad, bn.bias.grad) < 1e-4
+
+
+def test_maxpool_adam_misc():
+    from mcav import nn as N
+    import ctypes
+    from mcav import lib as L
+    g = torch.Generator().manual_seed(7)
+    x = torch.relu(torch.randn(2, 64, 11, 14, generator=g)).requires_grad_()   # ReLU zeros -> ties
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    yd, idx = N.maxpool_fwd(nhwc(x.detach()))
+    assert rel_err(nchw(yd), y) == 0
+    dx = N.maxpool_bwd(nhwc(dy), idx, (2, 11, 14, 64))
+    assert rel_err(nchw(dx), x.grad) < 1e-6
+    # Adam against torch.optim.Adam for 3 steps
+    p = torch.randn(1000, generator=g)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([ref], 1e-3)
+    pd, m, v = p.to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        L.check(L.lib().mcav_adam_step(N.P(pd), N.P(gr.to(DEV)), N.P(m), N.P(v), 1000, 1e-3, 0.9, 0.999, 1e-8, step, 1.0, L.stream()), "adam")
+    assert rel_err(pd, ref) < 1e-6
+    # spatial mean
+    t = torch.randn(3, 2, 5, 12, generator=g)
+    out = N.spatial_mean(t.to(DEV), 0.06)
+    assert rel_err(out, 0.06 * t.mean((1, 2))) < 1e-5

@@ -1,0 +1,98 @@
+// Source-side addressing of the implicit-GEMM convolution kernels (shared by the forward/dgrad kernel and the
+// wgrad kernel): how a destination pixel and a filter tap select the source pixel(s), with zero / reflection
+// padding, the fused nearest-upsample + channel-concat of the decoder, and the two adjoint gathers.
+#pragma once
+#include "mcav_common.h"
+#include "../../include/mcav_conv.h"
+
+namespace mcav {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CK = 16;         // K-tile depth: 16 input channels of one filter tap
+constexpr int LDK = CK + 4;    // LDS row stride (floats) of a [rows][CK] operand tile: conflict-free ds_read_b128
+
+struct GatherSrc {
+    const float* x1;
+    const float* x2;
+    int B, Hs, Ws, C1, C2, up1;
+    int mode, stride, sign, offset, pad_mode;
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+// 4 consecutive channels [c, c+4) of the logical (concatenated, possibly upsampled) source at pixel (n, sy, sx);
+// the caller guarantees 0 <= sy < Hs, 0 <= sx < Ws.  Channels past C1 + C2 read as zero.
+__device__ __forceinline__ f32x4 load_src4(const GatherSrc& g, int n, int sy, int sx, int c) {
+    const float* p;
+    int C, cc;
+    size_t pix;
+    if (c < g.C1) {
+        p = g.x1; C = g.C1; cc = c;
+        pix = g.up1 ? ((size_t)(n * (g.Hs >> 1) + (sy >> 1)) * (g.Ws >> 1) + (sx >> 1)) : ((size_t)(n * g.Hs + sy) * g.Ws + sx);
+    } else {
+        p = g.x2; C = g.C2; cc = c - g.C1;
+        pix = (size_t)(n * g.Hs + sy) * g.Ws + sx;
+    }
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (cc >= C) return v;                      // K padding beyond the real channels
+    const float* q = p + pix * C + cc;
+    if (((C & 3) == 0) && cc + 4 <= C) {
+        v = *reinterpret_cast<const f32x4*>(q);
+    } else {                                    // narrow tensors (C = 1 disparity maps): scalar, masked
+        if (cc + 0 < C) v.x = q[0];
+        if (cc + 1 < C) v.y = q[1];
+        if (cc + 2 < C) v.z = q[2];
+        if (cc + 3 < C) v.w = q[3];
+    }
+    return v;
+}
+
+// One element group of the A operand: destination pixel (n, dy, dx), filter tap (ky, kx), channels [c, c+4).
+__device__ __forceinline__ f32x4 gather4(const GatherSrc& g, int n, int dy, int dx, int ky, int kx, int c) {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (g.mode == MCAV_G_DIRECT || g.mode == MCAV_G_SMALLC) {
+        int sy = dy * g.stride + g.sign * ky + g.offset;
+        int sx = dx * g.stride + g.sign * kx + g.offset;
+        if (g.pad_mode == MCAV_PAD_REFLECT) {
+            sy = reflect_idx(sy, g.Hs);
+            sx = reflect_idx(sx, g.Ws);
+        } else if ((unsigned)sy >= (unsigned)g.Hs || (unsigned)sx >= (unsigned)g.Ws) {
+            return z;
+        }
+        return load_src4(g, n, sy, sx, c);
+    }
+    if (g.mode == MCAV_G_ADJ_REFLECT) {
+        // forward: y[o] = sum_k w[k] x[reflect(o + k - 1)], 3x3; so x[d] collects dy[d + 1 - k] plus, on the rows/cols next
+        // to the border, the output whose padded tap reflected onto d.
+        int ys[2], xs[2], ny = 0, nx = 0;
+        const int sy = dy + 1 - ky, sx = dx + 1 - kx;
+        if ((unsigned)sy < (unsigned)g.Hs) ys[ny++] = sy;
+        if (dy == 1 && ky == 0) ys[ny++] = 0;
+        if (dy == g.Hs - 2 && ky == 2) ys[ny++] = g.Hs - 1;
+        if ((unsigned)sx < (unsigned)g.Ws) xs[nx++] = sx;
+        if (dx == 1 && kx == 0) xs[nx++] = 0;
+        if (dx == g.Ws - 2 && kx == 2) xs[nx++] = g.Ws - 1;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) z += load_src4(g, n, ys[a], xs[b], c);
+        return z;
+    }
+    // MCAV_G_ADJ_STRIDE2: forward y[o] = sum_k w[k] x[2 o + k - pad]; x[d] collects dy[(d + pad - k) / 2] when that is whole
+    const int ty = dy + g.offset - ky, tx = dx + g.offset - kx;
+    if (ty < 0 || tx < 0 || ((ty | tx) & 1)) return z;
+    const int sy = ty >> 1, sx = tx >> 1;
+    if (sy >= g.Hs || sx >= g.Ws) return z;
+    return load_src4(g, n, sy, sx, c);
+}
+
+// XCD-aware bijective remap of a linear workgroup id: consecutive logical ids share an XCD (and its L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+}  // namespace mcav

@@ -1,0 +1,742 @@
+// Implicit-GEMM convolution for gfx950 on the fp32 MFMA (exact fp32: v_mfma_f32_32x32x2_f32 / 16x16x4_f32).
+//
+//   y[pix, n] = epilogue( sum_{tap, c} src(pix, tap)[c] * w[n][tap][c] )        (mcav_igemm: forward and dgrad)
+//   dw[n][tap][c] = sum_pix dy[pix, n] * src(pix, tap)[c]                         (mcav_wgrad)
+//
+// NHWC activations, packed [Np][taps][Kp] weights.  A 256-thread workgroup (4 wavefronts of 64) owns a BM x BN output
+// tile; the K loop walks (tap, 16-channel chunk) tiles.  Each tile's A panel [BM][16] is gathered from HBM/L2 with
+// 16-byte loads (4 lanes cover one pixel's 64 contiguous bytes), the B panel [BN][16] comes from the packed weights;
+// both are register-staged into double-buffered LDS (rows padded to 20 floats so the ds_read_b128 fragment reads
+// are bank-conflict free), the loads of tile t+1 are issued before the MFMAs of tile t, one barrier per tile.
+// Fragments: one ds_read_b128 gives a lane 4 consecutive k of its row; lane-group g takes k = 4g..4g+3 of each
+// 8- (32x32x2) or 16-deep (16x16x4) sub-step, A and B permuted identically, so the products are exact fp32 fmas.
+#include <type_traits>
+
+#include "conv_gather.h"
+
+namespace mcav {
+
+template <int BM_, int BN_, int WM_, int WN_, int MF_>
+struct Tile {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, MF = MF_;
+    static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
+    static constexpr int TM = WM / MF, TN = WN / MF;         // MFMA tiles per wavefront
+    static constexpr int ACC = MF == 32 ? 16 : 4;             // accumulator registers per MFMA tile
+    using AccT = typename std::conditional<MF_ == 32, f32x16, f32x4>::type;
+    static constexpr int AROWS = BM / 64;                     // A rows per thread per K-tile (4 lanes per row)
+    static constexpr int BVECS = (BN * 4 + 255) / 256;        // B float4 per thread per K-tile
+    static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per workgroup");
+    static_assert(BM % 64 == 0, "BM multiple of 64");
+};
+
+using Tile128x64 = Tile<128, 64, 64, 32, 32>;
+using Tile64x64 = Tile<64, 64, 32, 32, 32>;
+using Tile256x32 = Tile<256, 32, 64, 32, 32>;
+using Tile256x16 = Tile<256, 16, 64, 16, 16>;
+using Tile128x128 = Tile<128, 128, 64, 64, 32>;
+using Tile64x16 = Tile<64, 16, 16, 16, 16>;
+
+struct IgemmParams {
+    GatherSrc g;
+    const float* w;
+    int kh, kw, Kp, Kstride, taps;
+    float* y;
+    int Hd, Wd, Cd, n_begin, n_count, y_choff;
+    const float* bias;
+    int act;
+    const float* dact_aux;
+    int dact;
+    const float* addend;
+    int pool;
+    float* stats;
+    int M;           // rows of the GEMM (incl. class padding for ADJ_STRIDE2)
+    int Mc, McP;     // ADJ_STRIDE2: pixels per parity class and its BM-padded size
+    int mtiles, ntiles;
+};
+
+// destination pixel of GEMM row m: returns false for padding rows.
+__device__ __forceinline__ bool decode_row(const IgemmParams& p, int m, int& n, int& dy, int& dx) {
+    if (p.g.mode == MCAV_G_ADJ_STRIDE2) {
+        const int cls = m / p.McP, r = m - cls * p.McP;
+        if (r >= p.Mc) return false;
+        const int Hc = (p.Hd + 1) >> 1, Wc = (p.Wd + 1) >> 1;
+        n = r / (Hc * Wc);
+        const int q = r - n * (Hc * Wc);
+        const int y2 = q / Wc, x2 = q - y2 * Wc;
+        dy = 2 * y2 + (cls >> 1);
+        dx = 2 * x2 + (cls & 1);
+        return dy < p.Hd && dx < p.Wd;
+    }
+    if (m >= p.M) return false;
+    if (p.pool) {
+        const int blk = m >> 2, q = m & 3;
+        const int Hh = p.Hd >> 1, Wh = p.Wd >> 1;
+        n = blk / (Hh * Wh);
+        const int r = blk - n * (Hh * Wh);
+        const int y2 = r / Wh, x2 = r - y2 * Wh;
+        dy = 2 * y2 + (q >> 1);
+        dx = 2 * x2 + (q & 1);
+        return true;
+    }
+    n = m / (p.Hd * p.Wd);
+    const int r = m - n * (p.Hd * p.Wd);
+    dy = r / p.Wd;
+    dx = r - dy * p.Wd;
+    return true;
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == MCAV_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == MCAV_ACT_ELU) return v > 0.f ? v : expm1f(v);
+    if (act == MCAV_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+// derivative of the activation expressed through its OUTPUT y
+__device__ __forceinline__ float act_bwd(float y, int act) {
+    if (act == MCAV_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == MCAV_ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
+    if (act == MCAV_ACT_SIGMOID) return y * (1.f - y);
+    return 1.f;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+    constexpr int BM = T::BM, BN = T::BN;
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDK];
+    __shared__ int s_out[BM];
+    __shared__ float s_stat[T::WAVES_M][2][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = lid % p.ntiles, mt = lid / p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const GatherSrc& g = p.g;
+
+    // ---- per-thread A rows (4 lanes per row: c4 = 16-byte column of the 16-float K chunk)
+    const int c4 = tid & 3, r0 = tid >> 2;
+    int rn[T::AROWS], ry[T::AROWS], rx[T::AROWS];
+#pragma unroll
+    for (int j = 0; j < T::AROWS; ++j) {
+        int n, dy, dx;
+        const bool ok = decode_row(p, m0 + r0 + 64 * j, n, dy, dx);
+        rn[j] = ok ? n : -1; ry[j] = dy; rx[j] = dx;
+    }
+    // ---- epilogue table: destination pixel index of every tile row
+    for (int r = tid; r < BM; r += 256) {
+        int n, dy, dx;
+        const bool ok = decode_row(p, m0 + r, n, dy, dx);
+        int o = -1;
+        if (ok) o = p.pool ? ((n * (p.Hd >> 1) + (dy >> 1)) * (p.Wd >> 1) + (dx >> 1)) : ((n * p.Hd + dy) * p.Wd + dx);
+        s_out[r] = o;
+    }
+
+    // ---- K-tile enumeration: (tap, chunk); ADJ_STRIDE2 tiles only visit the taps of their parity class
+    const int nchunks = g.mode == MCAV_G_SMALLC ? 1 : p.Kp / CK;
+    int cls_py = 0, cls_px = 0;
+    if (g.mode == MCAV_G_ADJ_STRIDE2) { const int cls = m0 / p.McP; cls_py = cls >> 1; cls_px = cls & 1; }
+    auto tap_ok = [&](int tap) -> bool {
+        if (g.mode != MCAV_G_ADJ_STRIDE2) return true;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        return (((cls_py + g.offset - ky) | (cls_px + g.offset - kx)) & 1) == 0;
+    };
+    int T_total;
+    if (g.mode == MCAV_G_SMALLC) {
+        T_total = (p.taps * 4 + CK - 1) / CK;
+    } else {
+        int nv = 0;
+        for (int t = 0; t < p.taps; ++t) nv += tap_ok(t) ? 1 : 0;
+        T_total = nv * nchunks;
+    }
+    int tap = 0, chunk = 0;
+    if (g.mode != MCAV_G_SMALLC) while (tap < p.taps && !tap_ok(tap)) ++tap;
+
+    f32x4 ra[T::AROWS], rb[T::BVECS];
+    auto load_tile = [&]() {      // global -> registers for the tile at (tap, chunk)
+        int ky, kx, c, kflat;
+        if (g.mode == MCAV_G_SMALLC) {
+            const int t4 = chunk * 4 + c4;             // every 16-byte column is its own tap
+            ky = t4 / p.kw; kx = t4 - ky * p.kw; c = 0; kflat = chunk * CK;
+            if (t4 >= p.taps) ky = -1;
+        } else {
+            ky = tap / p.kw; kx = tap - ky * p.kw; c = chunk * CK + c4 * 4; kflat = tap * p.Kp + chunk * CK;
+        }
+#pragma unroll
+        for (int j = 0; j < T::AROWS; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (rn[j] >= 0 && ky >= 0) v = gather4(g, rn[j], ry[j], rx[j], ky, kx, c);
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < T::BVECS; ++j) {
+            const int e = tid + 256 * j, nn = e >> 2;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (nn < BN && n0 + nn < p.n_count)
+                v = *reinterpret_cast<const f32x4*>(p.w + (size_t)(p.n_begin + n0 + nn) * p.Kstride + kflat + (e & 3) * 4);
+            rb[j] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < T::AROWS; ++j) *reinterpret_cast<f32x4*>(&As[buf][r0 + 64 * j][c4 * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < T::BVECS; ++j) {
+            const int e = tid + 256 * j, nn = e >> 2;
+            if (nn < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nn][(e & 3) * 4]) = rb[j];
+        }
+    };
+    auto advance = [&]() {
+        if (g.mode == MCAV_G_SMALLC) { ++chunk; return; }
+        if (++chunk == nchunks) { chunk = 0; do { ++tap; } while (tap < p.taps && !tap_ok(tap)); }
+    };
+
+    // ---- accumulators
+    const int wm0 = (wave / T::WAVES_N) * T::WM, wn0 = (wave % T::WAVES_N) * T::WN;
+    typename T::AccT acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < T::ACC; ++r) acc[i][j][r] = 0.f;
+
+    if (T_total > 0) {
+        load_tile();
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < T_total; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T_total) { advance(); load_tile(); }
+        if constexpr (T::MF == 32) {
+            const int frow = lane & 31, fk = (lane >> 5) * 4;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f32x4 a[T::TM], b[T::TN];
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][wm0 + i * 32 + frow][ks * 8 + fk]);
+#pragma unroll
+                for (int j = 0; j < T::TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][wn0 + j * 32 + frow][ks * 8 + fk]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < T::TN; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+                        }
+            }
+        } else {
+            const int frow = lane & 15, fk = (lane >> 4) * 4;
+            f32x4 a[T::TM], b[T::TN];
+#pragma unroll
+            for (int i = 0; i < T::TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][wm0 + i * 16 + frow][fk]);
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][wn0 + j * 16 + frow][fk]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+                    }
+        }
+        if (t + 1 < T_total) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D layout: 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
+    //                           16x16: col = lane & 15, row = 4 (lane >> 4) + r.   Registers 4q..4q+3 are 4 consecutive rows.
+    constexpr int MF = T::MF;
+    const int ccol = lane & (MF - 1);
+    float ssum[T::TN], ssq[T::TN];
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) {
+            const int nl = n0 + wn0 + j * MF + ccol;          // column within this launch
+            const bool ncol = nl < p.n_count;
+            const float bv = (p.bias && ncol) ? p.bias[p.n_begin + nl] : 0.f;
+#pragma unroll
+            for (int q = 0; q < T::ACC / 4; ++q) {
+                const int rbase = wm0 + i * MF + (MF == 32 ? 8 * q + 4 * (lane >> 5) : 4 * (lane >> 4));
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fwd(acc[i][j][4 * q + e] + bv, p.act);
+                if (p.pool) {
+                    const int o = s_out[rbase];
+                    if (o >= 0 && ncol) {
+                        float s = (v[0] + v[1]) + (v[2] + v[3]);
+                        const size_t off = (size_t)o * p.Cd + p.y_choff + nl;
+                        if (p.dact_aux) s *= act_bwd(p.dact_aux[off], p.dact);
+                        if (p.addend) s += p.addend[off];
+                        p.y[off] = s;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int o = s_out[rbase + e];
+                        if (o >= 0 && ncol) {
+                            float s = v[e];
+                            const size_t off = (size_t)o * p.Cd + p.y_choff + nl;
+                            if (p.dact_aux) s *= act_bwd(p.dact_aux[off], p.dact);
+                            if (p.addend) s += p.addend[off];
+                            p.y[off] = s;
+                            ssum[j] += s;
+                            ssq[j] += s * s;
+                        }
+                    }
+                }
+            }
+        }
+    if (p.stats) {
+        // column sums over this workgroup's rows: lanes holding the same column, then the wavefronts stacked along M
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) {
+            if (MF == 32) {
+                ssum[j] += __shfl_xor(ssum[j], 32, 64);
+                ssq[j] += __shfl_xor(ssq[j], 32, 64);
+            } else {
+                ssum[j] += __shfl_xor(ssum[j], 16, 64); ssq[j] += __shfl_xor(ssq[j], 16, 64);
+                ssum[j] += __shfl_xor(ssum[j], 32, 64); ssq[j] += __shfl_xor(ssq[j], 32, 64);
+            }
+            if (lane < MF) {
+                s_stat[wave / T::WAVES_N][0][wn0 + j * MF + lane] = ssum[j];
+                s_stat[wave / T::WAVES_N][1][wn0 + j * MF + lane] = ssq[j];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * BN; e += 256) {
+            const int which = e / BN, col = e - which * BN;
+            if (n0 + col < p.n_count) {
+                float s = 0.f;
+#pragma unroll
+                for (int wmi = 0; wmi < T::WAVES_M; ++wmi) s += s_stat[wmi][which][col];
+                p.stats[((size_t)mt * 2 + which) * p.n_count + n0 + col] = s;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// out[kflat, n] = sum_pix A[pix, kflat] * dy[pix, n]: GEMM rows = flattened (tap, c) of the filter, columns = output
+// channels, reduction over pixels (split across workgroups; partial tiles go to a slab and are summed in fixed order).
+struct WgradParams {
+    GatherSrc g;
+    int kh, kw, Kp, taps, Ktot;   // Ktot = taps * Kp (GEMM rows)
+    const float* dy;
+    int Hd, Wd, Cdy, dy_choff, Cout;
+    int Mpix;                      // B * Hd * Wd
+    int splits, pix_per_split;     // pixel ranges per workgroup (multiple of KP)
+    int mtiles, ntiles;
+    float* slab;                   // [splits][Ktot][CoutP16]
+    int slabN;                     // row stride of the slab (Cout rounded up to 16)
+};
+
+constexpr int KP = 32;   // pixels per K-tile of the wgrad GEMM
+
+template <class T>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+    constexpr int BM = T::BM, BN = T::BN;
+    __shared__ __attribute__((aligned(16))) float Xs[2][KP][BM];   // [pixel][kflat]  (A operand, k-major)
+    __shared__ __attribute__((aligned(16))) float Ys[2][KP][BN];   // [pixel][n]      (B operand, k-major)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per_split = p.mtiles * p.ntiles;
+    const int split = blockIdx.x / per_split, rem = blockIdx.x - split * per_split;
+    const int nt = rem % p.ntiles, mt = rem / p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;      // m0: first kflat row, n0: first output channel
+    const GatherSrc& g = p.g;
+
+    // A loads: BM/4 float4 columns x KP pixels per tile; thread owns column group(s) and strides over pixels
+    constexpr int ACOLS = BM / 4;                       // float4 columns
+    constexpr int APIX = 256 / ACOLS;                   // pixels covered per pass (BM=128: 8, BM=64: 16, BM=256: 4)
+    constexpr int APASS = KP / APIX;
+    const int acol = tid % ACOLS, apix = tid / ACOLS;
+    const int kflat = m0 + acol * 4;
+    int aky = -1, akx = 0, ac = 0;
+    if (kflat < p.Ktot) {
+        const int tap = kflat / p.Kp;
+        ac = kflat - tap * p.Kp;
+        aky = tap / p.kw; akx = tap - aky * p.kw;
+        if (tap >= p.taps) aky = -1;
+    }
+    // B loads: BN/4 float4 columns x KP pixels
+    constexpr int BCOLS = BN / 4;
+    constexpr int BPIX = 256 / BCOLS > KP ? KP : 256 / BCOLS;
+    constexpr int BPASS = KP / BPIX;
+    const int bcol = tid % BCOLS, bpix = tid / BCOLS;
+
+    const int pix_begin = split * p.pix_per_split;
+    const int pix_end = min(p.Mpix, pix_begin + p.pix_per_split);
+    const int T_total = pix_end > pix_begin ? (pix_end - pix_begin + KP - 1) / KP : 0;
+
+    // destination pixel of this thread's first A row of the current tile, advanced incrementally (no per-tile division)
+    int pn, py, px;
+    {
+        const int m = pix_begin + apix;
+        pn = m / (p.Hd * p.Wd);
+        const int r = m - pn * (p.Hd * p.Wd);
+        py = r / p.Wd; px = r - py * p.Wd;
+    }
+    auto step_pix = [&](int& n, int& y, int& x, int by) {
+        x += by;
+        while (x >= p.Wd) { x -= p.Wd; if (++y == p.Hd) { y = 0; ++n; } }
+    };
+    f32x4 ra[APASS], rb[BPASS];
+    auto load_tile = [&](int t) {      // must be called with t = 0, 1, 2, ... in order
+        const int pb = pix_begin + t * KP;
+        int n = pn, dy = py, dx = px;
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) {
+            const int m = pb + apix + j * APIX;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < pix_end && aky >= 0) v = gather4(g, n, dy, dx, aky, akx, ac);
+            ra[j] = v;
+            step_pix(n, dy, dx, APIX);
+        }
+        pn = n; py = dy; px = dx;       // APASS * APIX == KP: now at this thread's first row of tile t + 1
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            const int pl = bpix + j * BPIX;
+            const int m = pb + pl;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pl < KP && m < pix_end) {
+                const int c = n0 + bcol * 4;
+                const float* q = p.dy + (size_t)m * p.Cdy + p.dy_choff + c;
+                if ((p.Cdy & 3) == 0 && (p.dy_choff & 3) == 0 && c + 4 <= p.Cout) {
+                    v = *reinterpret_cast<const f32x4*>(q);
+                } else {
+                    if (c + 0 < p.Cout) v.x = q[0];
+                    if (c + 1 < p.Cout) v.y = q[1];
+                    if (c + 2 < p.Cout) v.z = q[2];
+                    if (c + 3 < p.Cout) v.w = q[3];
+                }
+            }
+            rb[j] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) *reinterpret_cast<f32x4*>(&Xs[buf][apix + j * APIX][acol * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            const int pl = bpix + j * BPIX;
+            if (pl < KP) *reinterpret_cast<f32x4*>(&Ys[buf][pl][bcol * 4]) = rb[j];
+        }
+    };
+
+    const int wm0 = (wave / T::WAVES_N) * T::WM, wn0 = (wave % T::WAVES_N) * T::WN;
+    typename T::AccT acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < T::ACC; ++r) acc[i][j][r] = 0.f;
+
+    if (T_total > 0) { load_tile(0); store_tile(0); }
+    __syncthreads();
+    for (int t = 0; t < T_total; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T_total) load_tile(t + 1);
+        if constexpr (T::MF == 32) {
+            const int fr = lane & 31, fk = lane >> 5;
+#pragma unroll
+            for (int kk = 0; kk < KP / 2; ++kk) {
+                float a[T::TM], b[T::TN];
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i) a[i] = Xs[buf][kk * 2 + fk][wm0 + i * 32 + fr];
+#pragma unroll
+                for (int j = 0; j < T::TN; ++j) b[j] = Ys[buf][kk * 2 + fk][wn0 + j * 32 + fr];
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
+            const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+            for (int kk = 0; kk < KP / 4; ++kk) {
+                float a[T::TM], b[T::TN];
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i) a[i] = Xs[buf][kk * 4 + fk][wm0 + i * 16 + fr];
+#pragma unroll
+                for (int j = 0; j < T::TN; ++j) b[j] = Ys[buf][kk * 4 + fk][wn0 + j * 16 + fr];
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        if (t + 1 < T_total) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    constexpr int MF = T::MF;
+    const int ccol = lane & (MF - 1);
+    float* slab = p.slab + (size_t)split * p.Ktot * p.slabN;
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) {
+            const int n = n0 + wn0 + j * MF + ccol;
+#pragma unroll
+            for (int r = 0; r < T::ACC; ++r) {
+                const int row = m0 + wm0 + i * MF + (MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) : 4 * (lane >> 4) + r);
+                if (row < p.Ktot && n < p.slabN) slab[(size_t)row * p.slabN + n] = acc[i][j][r];
+            }
+        }
+}
+
+// slab [splits][Ktot][slabN] -> OIHW gradient (fixed summation order; optional accumulate)
+__global__ void wgrad_reduce_kernel(const float* slab, int splits, int Ktot, int slabN, int Kp, int taps, int Cout, int Cin, float* dw, int accumulate) {
+    const int total = Cout * Cin * taps;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int co = e / (Cin * taps), r = e - co * (Cin * taps);
+        const int ci = r / taps, tap = r - ci * taps;
+        const size_t src = (size_t)(tap * Kp + ci) * slabN + co;
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slab[(size_t)k * Ktot * slabN + src];
+        dw[e] = accumulate ? dw[e] + s : s;
+    }
+}
+
+// column sums of dy over pixels -> dbias (two-stage, fixed order)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* dy, int Mpix, int Cdy, int choff, int Cout, float* part, int nblk) {
+    // block handles pixel range; thread t handles channel t % Cq ... generic strided accumulation
+    const int per = (Mpix + nblk - 1) / nblk;
+    const int pb = blockIdx.x * per, pe = min(Mpix, pb + per);
+    for (int c = threadIdx.x; c < Cout; c += 256) {
+        float s = 0.f;
+        for (int m = pb; m < pe; ++m) s += dy[(size_t)m * Cdy + choff + c];
+        part[(size_t)blockIdx.x * Cout + c] = s;
+    }
+}
+
+__global__ void colsum_final_kernel(const float* part, int nblk, int Cout, float* out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cout) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * Cout + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+// OIHW -> packed.  transposed = 0: packed[n = co][tap][k = ci];  transposed = 1: packed[n = ci][tap][k = co].
+__global__ void pack_weights_kernel(const float* w, int Cout, int Cin, int taps, int transposed, float* packed, int Np, int Kp, int Kstride) {
+    const size_t total = (size_t)Np * Kstride;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(e / Kstride), kf = (int)(e - (size_t)n * Kstride);
+        const int tap = kf / Kp, k = kf - tap * Kp;
+        float v = 0.f;
+        if (tap < taps) {
+            const int co = transposed ? k : n, ci = transposed ? n : k;
+            if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * taps + tap];
+        }
+        packed[e] = v;
+    }
+}
+
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+inline int kstride_of(int taps, int Kp) { return round_up(taps * Kp, CK); }
+
+inline int pick_tile(const mcav_igemm_desc* d, long M) {
+    if (d->tile) return d->tile;
+    if (d->n_count <= 16) return M >= 256 * 64 ? 4 : 6;
+    if (d->n_count <= 32) return 3;
+    const long t128x64 = ((M + 127) / 128) * ((d->n_count + 63) / 64);
+    if (d->n_count >= 128 && ((M + 127) / 128) * ((d->n_count + 127) / 128) >= 512) return 5;
+    if (t128x64 >= 384) return 1;
+    return 2;
+}
+
+inline void tile_dims(int id, int& BM, int& BN) {
+    switch (id) {
+        case 1: BM = 128; BN = 64; break;
+        case 2: BM = 64; BN = 64; break;
+        case 3: BM = 256; BN = 32; break;
+        case 4: BM = 256; BN = 16; break;
+        case 5: BM = 128; BN = 128; break;
+        default: BM = 64; BN = 16; break;
+    }
+}
+
+inline bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
+    if (!d || !d->x1 || !d->w || !d->y) return false;
+    if (d->B <= 0 || d->Hs <= 0 || d->Ws <= 0 || d->Hd <= 0 || d->Wd <= 0 || d->C1 <= 0 || d->C2 < 0) return false;
+    if (d->C2 > 0 && !d->x2) return false;
+    if (d->kh <= 0 || d->kw <= 0 || d->Np <= 0 || d->Kp <= 0) return false;
+    if (d->n_begin < 0 || d->n_count <= 0 || d->n_begin + d->n_count > d->Np) return false;
+    if (d->mode == MCAV_G_SMALLC) { if (d->Kp != 4 || d->C1 != 4 || d->C2 != 0) return false; }
+    else if (d->Kp % CK != 0 || d->Kp < d->C1 + d->C2) return false;
+    if (d->C2 > 0 && (d->C1 % 4 != 0)) return false;
+    if (d->mode == MCAV_G_ADJ_REFLECT && (d->kh != 3 || d->kw != 3 || d->Hs != d->Hd || d->Ws != d->Wd || d->Hs < 2 || d->Ws < 2)) return false;
+    if (d->pad_mode == MCAV_PAD_REFLECT && (d->Hs < 2 || d->Ws < 2)) return false;
+    if (d->up1 && ((d->Hs & 1) || (d->Ws & 1))) return false;
+    if (d->pool && ((d->Hd & 1) || (d->Wd & 1) || d->mode == MCAV_G_ADJ_STRIDE2)) return false;
+    if (d->pool && d->stats) return false;
+    p.g.x1 = d->x1; p.g.x2 = d->x2; p.g.B = d->B; p.g.Hs = d->Hs; p.g.Ws = d->Ws; p.g.C1 = d->C1; p.g.C2 = d->C2; p.g.up1 = d->up1;
+    p.g.mode = d->mode; p.g.stride = d->stride; p.g.sign = d->sign; p.g.offset = d->offset; p.g.pad_mode = d->pad_mode;
+    p.w = d->w; p.kh = d->kh; p.kw = d->kw; p.Kp = d->Kp; p.taps = d->kh * d->kw; p.Kstride = kstride_of(p.taps, d->Kp);
+    p.y = d->y; p.Hd = d->Hd; p.Wd = d->Wd; p.Cd = d->Cd; p.n_begin = d->n_begin; p.n_count = d->n_count; p.y_choff = d->y_choff;
+    p.bias = d->bias; p.act = d->act; p.dact_aux = d->dact_aux; p.dact = d->dact; p.addend = d->addend; p.pool = d->pool; p.stats = d->stats;
+    const long Mlin = (long)d->B * d->Hd * d->Wd;
+    tile = pick_tile(d, Mlin);
+    int BM, BN;
+    tile_dims(tile, BM, BN);
+    if (d->mode == MCAV_G_ADJ_STRIDE2) {
+        p.Mc = d->B * ((d->Hd + 1) / 2) * ((d->Wd + 1) / 2);
+        p.McP = round_up(p.Mc, BM);
+        p.M = 4 * p.McP;
+    } else {
+        p.Mc = 0; p.McP = 1;
+        if (Mlin > 0x7fffffffL) return false;
+        p.M = (int)Mlin;
+    }
+    p.mtiles = (p.M + BM - 1) / BM;
+    p.ntiles = (d->n_count + BN - 1) / BN;
+    return true;
+}
+
+template <class T>
+inline void launch_igemm(const IgemmParams& p, hipStream_t s) {
+    igemm_kernel<T><<<p.mtiles * p.ntiles, 256, 0, s>>>(p);
+}
+
+}  // namespace mcav
+
+using namespace mcav;
+
+MCAV_EXPORT int mcav_igemm_mtiles(const mcav_igemm_desc* d) {
+    IgemmParams p;
+    int tile;
+    if (!fill_params(d, p, tile)) return MCAV_E_INVALID;
+    return p.mtiles;
+}
+
+MCAV_EXPORT int mcav_igemm(const mcav_igemm_desc* d, void* stream) {
+    IgemmParams p;
+    int tile;
+    if (!fill_params(d, p, tile)) return MCAV_E_INVALID;
+    hipStream_t s = as_stream(stream);
+    switch (tile) {
+        case 1: launch_igemm<Tile128x64>(p, s); break;
+        case 2: launch_igemm<Tile64x64>(p, s); break;
+        case 3: launch_igemm<Tile256x32>(p, s); break;
+        case 4: launch_igemm<Tile256x16>(p, s); break;
+        case 5: launch_igemm<Tile128x128>(p, s); break;
+        case 6: launch_igemm<Tile64x16>(p, s); break;
+        default: return MCAV_E_INVALID;
+    }
+    return launch_status();
+}
+
+namespace mcav {
+
+struct WgradPlan {
+    WgradParams p;
+    int tile;
+    size_t slab_bytes, part_bytes;
+    int colsum_blocks;
+};
+
+inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
+    if (!d || !d->x1 || !d->dy || !d->dw_oihw) return false;
+    if (d->B <= 0 || d->Hs <= 0 || d->Ws <= 0 || d->Hd <= 0 || d->Wd <= 0 || d->C1 <= 0 || d->C2 < 0 || d->Cout <= 0 || d->Cin <= 0) return false;
+    if (d->C2 > 0 && (!d->x2 || d->C1 % 4 != 0)) return false;
+    if (d->mode != MCAV_G_DIRECT && d->mode != MCAV_G_SMALLC) return false;
+    if (d->mode == MCAV_G_SMALLC && (d->Kp != 4 || d->C1 != 4 || d->C2 != 0)) return false;
+    if (d->mode == MCAV_G_DIRECT && (d->Kp % CK != 0 || d->Kp < d->C1 + d->C2)) return false;
+    if (d->Cin > d->Kp) return false;
+    WgradParams& p = pl.p;
+    p.g.x1 = d->x1; p.g.x2 = d->x2; p.g.B = d->B; p.g.Hs = d->Hs; p.g.Ws = d->Ws; p.g.C1 = d->C1; p.g.C2 = d->C2; p.g.up1 = d->up1;
+    p.g.mode = d->mode; p.g.stride = d->stride; p.g.sign = d->sign; p.g.offset = d->offset; p.g.pad_mode = d->pad_mode;
+    p.kh = d->kh; p.kw = d->kw; p.Kp = d->Kp; p.taps = d->kh * d->kw; p.Ktot = p.taps * d->Kp;
+    p.dy = d->dy; p.Hd = d->Hd; p.Wd = d->Wd; p.Cdy = d->Cdy; p.dy_choff = d->dy_choff; p.Cout = d->Cout;
+    const long M = (long)d->B * d->Hd * d->Wd;
+    if (M > 0x7fffffffL) return false;
+    p.Mpix = (int)M;
+    p.slabN = round_up(d->Cout, 16);
+    int tile = d->tile;
+    if (!tile) {
+        if (d->Cout <= 16) tile = round_up(p.Ktot, 64) < round_up(p.Ktot, 256) ? 6 : 4;
+        else if (d->Cout <= 32) tile = 3;
+        else tile = p.Ktot <= 64 ? 2 : 1;
+    }
+    if (tile != 1 && tile != 2 && tile != 3 && tile != 4 && tile != 6) return false;
+    pl.tile = tile;
+    int BM, BN;
+    tile_dims(tile, BM, BN);
+    p.mtiles = (p.Ktot + BM - 1) / BM;
+    p.ntiles = (d->Cout + BN - 1) / BN;
+    const int out_tiles = p.mtiles * p.ntiles;
+    int splits = (1024 + out_tiles - 1) / out_tiles;             // aim at ~1024 workgroups
+    const int max_splits = (p.Mpix + 8 * KP - 1) / (8 * KP);     // but at least 8 K-tiles each
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.pix_per_split = round_up((p.Mpix + splits - 1) / splits, KP);
+    p.splits = (p.Mpix + p.pix_per_split - 1) / p.pix_per_split;
+    pl.slab_bytes = align_up(sizeof(float) * (size_t)p.splits * p.Ktot * p.slabN, 256);
+    pl.colsum_blocks = 256;
+    pl.part_bytes = align_up(sizeof(float) * (size_t)pl.colsum_blocks * d->Cout, 256);
+    return true;
+}
+
+template <class T>
+inline void launch_wgrad(const WgradParams& p, hipStream_t s) {
+    wgrad_kernel<T><<<p.splits * p.mtiles * p.ntiles, 256, 0, s>>>(p);
+}
+
+}  // namespace mcav
+
+MCAV_EXPORT size_t mcav_wgrad_workspace_bytes(const mcav_wgrad_desc* d) {
+    WgradPlan pl;
+    if (!plan_wgrad(d, pl)) return 0;
+    return pl.slab_bytes + pl.part_bytes;
+}
+
+MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    WgradPlan pl;
+    if (!plan_wgrad(d, pl) || !workspace) return MCAV_E_INVALID;
+    if (workspace_bytes < pl.slab_bytes + pl.part_bytes) return MCAV_E_WORKSPACE;
+    hipStream_t s = as_stream(stream);
+    pl.p.slab = reinterpret_cast<float*>(workspace);
+    float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pl.slab_bytes);
+    switch (pl.tile) {
+        case 1: launch_wgrad<Tile128x64>(pl.p, s); break;
+        case 2: launch_wgrad<Tile64x64>(pl.p, s); break;
+        case 3: launch_wgrad<Tile256x32>(pl.p, s); break;
+        case 4: launch_wgrad<Tile256x16>(pl.p, s); break;
+        case 6: launch_wgrad<Tile64x16>(pl.p, s); break;
+        default: return MCAV_E_INVALID;
+    }
+    const int total = d->Cout * d->Cin * pl.p.taps;
+    wgrad_reduce_kernel<<<min((total + 255) / 256, 2048), 256, 0, s>>>(pl.p.slab, pl.p.splits, pl.p.Ktot, pl.p.slabN, pl.p.Kp, pl.p.taps, d->Cout,
+                                                                       d->Cin, d->dw_oihw, d->accumulate);
+    if (d->dbias) {
+        colsum_partial_kernel<<<pl.colsum_blocks, 256, 0, s>>>(d->dy, pl.p.Mpix, d->Cdy, d->dy_choff, d->Cout, part, pl.colsum_blocks);
+        colsum_final_kernel<<<(d->Cout + 63) / 64, 64, 0, s>>>(part, pl.colsum_blocks, d->Cout, d->dbias, d->accumulate);
+    }
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_pack_weights(const float* w_oihw, int Cout, int Cin, int kh, int kw, int transposed, float* packed, int Np, int Kp,
+                                  void* stream) {
+    if (!w_oihw || !packed || Cout <= 0 || Cin <= 0 || kh <= 0 || kw <= 0 || Np <= 0 || Kp <= 0) return MCAV_E_INVALID;
+    if (!transposed && (Np < Cout || Kp < Cin)) return MCAV_E_INVALID;
+    if (transposed && (Np < Cin || Kp < Cout)) return MCAV_E_INVALID;
+    const int taps = kh * kw, Kstride = kstride_of(taps, Kp);
+    const size_t total = (size_t)Np * Kstride;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    pack_weights_kernel<<<blocks, 256, 0, as_stream(stream)>>>(w_oihw, Cout, Cin, taps, transposed, packed, Np, Kp, Kstride);
+    return launch_status();
+}

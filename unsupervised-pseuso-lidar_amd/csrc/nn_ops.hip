@@ -1,0 +1,401 @@
+// HBM-bound network kernels for gfx950: layout conversion, BatchNorm (training statistics / apply / backward),
+// MaxPool 3x3 s2, activation backward, spatial mean, fused Adam.  All NHWC, 16-byte accesses, grid-stride loops;
+// reductions are two-stage (per-block partials, fixed-order finalize in fp64) so results are run-to-run identical.
+#include "conv_gather.h"
+
+namespace mcav {
+
+inline int grid_for(size_t work_items, int per_block = 256, int cap = 4096) {
+    size_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (int)(b < (size_t)cap ? b : (size_t)cap);
+}
+
+// ---------------------------------------------------------------------------------------------- layout
+__global__ void nchw_to_nhwc_kernel(const float* src, int B, int C, int H, int W, float* dst, int Cp, int choff) {
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / plane, pix = i - b * plane;
+        for (int c = 0; c < C; ++c) dst[i * Cp + choff + c] = src[(b * C + c) * plane + pix];
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* src, int B, int C, int H, int W, int Cp, int choff, float* dst) {
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / plane, pix = i - b * plane;
+        for (int c = 0; c < C; ++c) dst[(b * C + c) * plane + pix] = src[i * Cp + choff + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- BatchNorm
+// stats: [mtiles][2][C] per-tile sums of x and x^2 (from the conv epilogue).  32 channels x 8 tile-slices per block.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, int mtiles, int C, double count, const float* gamma, const float* beta,
+                                                          float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                                                          float* shift, float* save_mean, float* save_invstd) {
+    __shared__ double s1[8][32], s2[8][32];
+    const int cl = threadIdx.x & 31, part = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int t = part; t < mtiles; t += 8) {
+            a += (double)stats[((size_t)t * 2 + 0) * C + c];
+            b += (double)stats[((size_t)t * 2 + 1) * C + c];
+        }
+    s1[part][cl] = a; s2[part][cl] = b;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        const double mean = a / count;
+        double var = b / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        save_mean[c] = (float)mean;
+        save_invstd[c] = invstd;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const f32x4* x, const f32x4* scale, const f32x4* shift, const f32x4* res, int relu, size_t n4, int C4, f32x4* y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        f32x4 v = x[i] * scale[c] + shift[c];
+        if (res) v += res[i];
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        y[i] = v;
+    }
+}
+
+__device__ __forceinline__ f32x4 relu_mask(f32x4 g, f32x4 y) {
+    g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f; g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+    return g;
+}
+
+// Per-block partial sums of dz and dz * xhat.  G = C/4 channel groups; a block covers PL = 256 / min(G,256) pixel lanes.
+constexpr int BNR_BLOCKS = 512;
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* dy, const f32x4* yact, const f32x4* x, const f32x4* mean, const f32x4* invstd,
+                                                            int relu, size_t n_pix, int C4, float* part /* [blocks][2][C] */) {
+    __shared__ f32x4 sh[2][256];
+    const size_t per = (n_pix + gridDim.x - 1) / gridDim.x;
+    const size_t pb = (size_t)blockIdx.x * per, pe = pb + per < n_pix ? pb + per : n_pix;
+    for (int g0 = 0; g0 < C4; g0 += 256) {
+        const int G = C4 - g0 < 256 ? C4 - g0 : 256;
+        const int PL = 256 / G;
+        const int cg = threadIdx.x % G, pl = threadIdx.x / G;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (pl < PL) {
+            const f32x4 mu = mean[g0 + cg], is = invstd[g0 + cg];
+            for (size_t m = pb + pl; m < pe; m += PL) {
+                const size_t i = m * C4 + g0 + cg;
+                f32x4 g = dy[i];
+                if (relu) g = relu_mask(g, yact[i]);
+                s1 += g;
+                s2 += g * ((x[i] - mu) * is);
+            }
+        }
+        sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2;
+        __syncthreads();
+        if (threadIdx.x < G) {
+            f32x4 a = sh[0][threadIdx.x], b = sh[1][threadIdx.x];
+            for (int k = 1; k < PL; ++k) { a += sh[0][threadIdx.x + k * G]; b += sh[1][threadIdx.x + k * G]; }
+            float* o = part + (size_t)blockIdx.x * 2 * C4 * 4;
+            *reinterpret_cast<f32x4*>(o + (size_t)(g0 + threadIdx.x) * 4) = a;
+            *reinterpret_cast<f32x4*>(o + (size_t)C4 * 4 + (size_t)(g0 + threadIdx.x) * 4) = b;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* part, int nblk, int C, float* dgamma, float* dbeta, int accumulate, float* sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        a += (double)part[(size_t)k * 2 * C + c];
+        b += (double)part[(size_t)k * 2 * C + C + c];
+    }
+    sums[c] = (float)a;
+    sums[C + c] = (float)b;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* dy, const f32x4* yact, const f32x4* x, const f32x4* gamma, const f32x4* mean,
+                                                           const f32x4* invstd, const f32x4* sums, int relu, size_t n4, int C4, float inv_count,
+                                                           f32x4* dx, f32x4* dres, int dres_acc) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        f32x4 g = dy[i];
+        if (relu) g = relu_mask(g, yact[i]);
+        if (dres) dres[i] = dres_acc ? dres[i] + g : g;
+        const f32x4 is = invstd[c];
+        const f32x4 xh = (x[i] - mean[c]) * is;
+        dx[i] = (gamma[c] * is) * (g - sums[c] * inv_count - xh * (sums[C4 + c] * inv_count));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- MaxPool 3x3 s2 p1
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, int B, int H, int W, int C, int Ho, int Wo, float* y, uint8_t* idx) {
+    const int C4 = C >> 2;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const float ninf = -__builtin_huge_valf();
+        f32x4 best = {ninf, ninf, ninf, ninf};
+        int bi[4] = {0, 0, 0, 0};
+        bool first[4] = {true, true, true, true};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)(b * H + iy) * W + ix) * C + c * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // torch's rule: take a new value when it is greater or NaN; the first in-bounds element initialises
+                    if (first[e] || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = ky * 3 + kx; first[e] = false; }
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = best;
+        uchar4 o;
+        o.x = (uint8_t)bi[0]; o.y = (uint8_t)bi[1]; o.z = (uint8_t)bi[2]; o.w = (uint8_t)bi[3];
+        *reinterpret_cast<uchar4*>(idx + i * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, const uint8_t* idx, int B, int H, int W, int C, int Ho, int Wo, float* dx, int accumulate) {
+    const int C4 = C >> 2;
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const int b = (int)(r / H);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        // windows (oy, ox) with oy*2-1 <= iy <= oy*2+1
+        const int oy_lo = iy >> 1, oy_hi = (iy + 1) >> 1;     // ceil((iy-1)/2) = iy>>1 for iy >= 0 ; floor((iy+1)/2)
+        const int ox_lo = ix >> 1, ox_hi = (ix + 1) >> 1;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (oy >= Ho) continue;
+            const int ky = iy - (oy * 2 - 1);
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (ox >= Wo) continue;
+                const int kx = ix - (ox * 2 - 1);
+                const int tap = ky * 3 + kx;
+                const size_t o = ((size_t)(b * Ho + oy) * Wo + ox) * C + c * 4;
+                const uchar4 k = *reinterpret_cast<const uchar4*>(idx + o);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+                if (k.x == tap) g.x += d.x;
+                if (k.y == tap) g.y += d.y;
+                if (k.z == tap) g.z += d.z;
+                if (k.w == tap) g.w += d.w;
+            }
+        }
+        f32x4* out = reinterpret_cast<f32x4*>(dx + i * 4);
+        *out = accumulate ? *out + g : g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- elementwise
+__device__ __forceinline__ float dact(float y, int act) {
+    if (act == MCAV_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == MCAV_ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
+    if (act == MCAV_ACT_SIGMOID) return y * (1.f - y);
+    return 1.f;
+}
+
+__global__ void act_bwd_kernel(const float* dy, const float* y, int act, size_t n, float* dx, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = dy[i] * dact(y[i], act);
+        dx[i] = accumulate ? dx[i] + v : v;
+    }
+}
+
+__global__ void add_kernel(const float* a, const float* b, size_t n, float* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+
+__global__ void spatial_mean_kernel(const float* x, int B, int n_pix, int C, float scale, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    float s = 0.f;
+    for (int p = 0; p < n_pix; ++p) s += x[((size_t)b * n_pix + p) * C + c];
+    out[i] = scale * (s / (float)n_pix);
+}
+
+__global__ void spatial_mean_bwd_kernel(const float* dout, int B, int n_pix, int C, float scale, float* dx) {
+    const size_t total = (size_t)B * n_pix * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int b = (int)(i / ((size_t)n_pix * C));
+        dx[i] = dout[b * C + c] * (scale / (float)n_pix);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2_sqrt, float gscale) {
+    const float step = lr / bc1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gr = g[i] * gscale;
+        const float mi = m[i] + (gr - m[i]) * (1.f - b1);     // exp_avg.lerp_(grad, 1 - beta1), as torch.optim.Adam
+        const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step * (mi / denom);
+    }
+}
+
+}  // namespace mcav
+
+using namespace mcav;
+
+MCAV_EXPORT int mcav_nchw_to_nhwc(const float* src, int B, int C, int H, int W, float* dst, int Cp, int choff, void* stream) {
+    if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || choff < 0 || choff + C > Cp) return MCAV_E_INVALID;
+    nchw_to_nhwc_kernel<<<grid_for((size_t)B * H * W), 256, 0, as_stream(stream)>>>(src, B, C, H, W, dst, Cp, choff);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_nhwc_to_nchw(const float* src, int B, int C, int H, int W, int Cp, int choff, float* dst, void* stream) {
+    if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || choff < 0 || choff + C > Cp) return MCAV_E_INVALID;
+    nhwc_to_nchw_kernel<<<grid_for((size_t)B * H * W), 256, 0, as_stream(stream)>>>(src, B, C, H, W, Cp, choff, dst);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_bn_finalize(const float* stats, int mtiles, int C, double count, const float* gamma, const float* beta, float eps, float momentum,
+                                 float* running_mean, float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
+                                 void* stream) {
+    if (!stats || !gamma || !beta || !scale || !shift || !save_mean || !save_invstd || mtiles <= 0 || C <= 0 || count <= 0) return MCAV_E_INVALID;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return MCAV_E_INVALID;
+    bn_finalize_kernel<<<(C + 31) / 32, 256, 0, as_stream(stream)>>>(stats, mtiles, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale,
+                                                                      shift, save_mean, save_invstd);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
+                                    float* scale, float* shift, void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0) return MCAV_E_INVALID;
+    bn_eval_coeffs_kernel<<<(C + 63) / 64, 64, 0, as_stream(stream)>>>(gamma, beta, running_mean, running_var, eps, C, scale, shift);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, int act, size_t n_pix, int C, float* y,
+                              void* stream) {
+    if (!x || !scale || !shift || !y || C <= 0 || (C & 3) || (act != MCAV_ACT_NONE && act != MCAV_ACT_RELU)) return MCAV_E_INVALID;
+    if (n_pix == 0) return MCAV_OK;
+    const size_t n4 = n_pix * (size_t)(C / 4);
+    bn_apply_kernel<<<grid_for(n4), 256, 0, as_stream(stream)>>>((const f32x4*)x, (const f32x4*)scale, (const f32x4*)shift, (const f32x4*)residual,
+                                                                 act == MCAV_ACT_RELU, n4, C / 4, (f32x4*)y);
+    return launch_status();
+}
+
+MCAV_EXPORT size_t mcav_bn_bwd_workspace_bytes(size_t n_pix, int C) {
+    (void)n_pix;
+    return C > 0 ? align_up(sizeof(float) * 2 * (size_t)C * BNR_BLOCKS, 256) : 0;
+}
+
+MCAV_EXPORT int mcav_bn_bwd_reduce(const float* dy, const float* y_act, const float* x, const float* save_mean, const float* save_invstd, int relu,
+                                   size_t n_pix, int C, float* dgamma, float* dbeta, int accumulate, float* sums, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    if (!dy || !x || !save_mean || !save_invstd || !sums || !workspace || C <= 0 || (C & 3) || n_pix == 0) return MCAV_E_INVALID;
+    if (relu && !y_act) return MCAV_E_INVALID;
+    const int C4 = C / 4;
+    if (C4 < 256 && (256 % C4) != 0) return MCAV_E_INVALID;
+    if (C4 > 256 && (C4 % 256) != 0) return MCAV_E_INVALID;
+    if (workspace_bytes < mcav_bn_bwd_workspace_bytes(n_pix, C)) return MCAV_E_WORKSPACE;
+    int blocks = (int)(n_pix < (size_t)BNR_BLOCKS ? n_pix : (size_t)BNR_BLOCKS);
+    float* part = reinterpret_cast<float*>(workspace);
+    hipStream_t s = as_stream(stream);
+    bn_bwd_reduce_kernel<<<blocks, 256, 0, s>>>((const f32x4*)dy, (const f32x4*)y_act, (const f32x4*)x, (const f32x4*)save_mean, (const f32x4*)save_invstd,
+                                                relu, n_pix, C4, part);
+    bn_bwd_finalize_kernel<<<(C + 63) / 64, 64, 0, s>>>(part, blocks, C, dgamma, dbeta, accumulate, sums);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_bn_bwd_apply(const float* dy, const float* y_act, const float* x, const float* gamma, const float* save_mean,
+                                  const float* save_invstd, const float* sums, int relu, size_t n_pix, int C, float* dx, float* dres,
+                                  int dres_accumulate, void* stream) {
+    if (!dy || !x || !gamma || !save_mean || !save_invstd || !sums || !dx || C <= 0 || (C & 3) || n_pix == 0) return MCAV_E_INVALID;
+    if (relu && !y_act) return MCAV_E_INVALID;
+    const size_t n4 = n_pix * (size_t)(C / 4);
+    bn_bwd_apply_kernel<<<grid_for(n4), 256, 0, as_stream(stream)>>>((const f32x4*)dy, (const f32x4*)y_act, (const f32x4*)x, (const f32x4*)gamma,
+                                                                     (const f32x4*)save_mean, (const f32x4*)save_invstd, (const f32x4*)sums, relu, n4,
+                                                                     C / 4, (float)(1.0 / (double)n_pix), (f32x4*)dx, (f32x4*)dres, dres_accumulate);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_maxpool3s2_fwd(const float* x, int B, int H, int W, int C, float* y, uint8_t* idx, void* stream) {
+    if (!x || !y || !idx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MCAV_E_INVALID;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    maxpool_fwd_kernel<<<grid_for((size_t)B * Ho * Wo * (C / 4)), 256, 0, as_stream(stream)>>>(x, B, H, W, C, Ho, Wo, y, idx);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_maxpool3s2_bwd(const float* dy, const uint8_t* idx, int B, int H, int W, int C, float* dx, int accumulate, void* stream) {
+    if (!dy || !idx || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MCAV_E_INVALID;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    maxpool_bwd_kernel<<<grid_for((size_t)B * H * W * (C / 4)), 256, 0, as_stream(stream)>>>(dy, idx, B, H, W, C, Ho, Wo, dx, accumulate);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_act_bwd(const float* dy, const float* y, int act, size_t n, float* dx, int accumulate, void* stream) {
+    if (!dy || !y || !dx) return MCAV_E_INVALID;
+    if (n == 0) return MCAV_OK;
+    act_bwd_kernel<<<grid_for(n), 256, 0, as_stream(stream)>>>(dy, y, act, n, dx, accumulate);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_add(const float* a, const float* b, size_t n, float* out, void* stream) {
+    if (!a || !b || !out) return MCAV_E_INVALID;
+    if (n == 0) return MCAV_OK;
+    add_kernel<<<grid_for(n), 256, 0, as_stream(stream)>>>(a, b, n, out);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_spatial_mean(const float* x, int B, int n_pix, int C, float scale, float* out, void* stream) {
+    if (!x || !out || B <= 0 || n_pix <= 0 || C <= 0) return MCAV_E_INVALID;
+    spatial_mean_kernel<<<(B * C + 63) / 64, 64, 0, as_stream(stream)>>>(x, B, n_pix, C, scale, out);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_spatial_mean_bwd(const float* dout, int B, int n_pix, int C, float scale, float* dx, void* stream) {
+    if (!dout || !dx || B <= 0 || n_pix <= 0 || C <= 0) return MCAV_E_INVALID;
+    spatial_mean_bwd_kernel<<<grid_for((size_t)B * n_pix * C), 256, 0, as_stream(stream)>>>(dout, B, n_pix, C, scale, dx);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                               float eps, int step, float grad_scale, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return MCAV_E_INVALID;
+    if (n == 0) return MCAV_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    adam_kernel<<<grid_for(n, 256, 8192), 256, 0, as_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1,
+                                                                       (float)sqrt(bc2), grad_scale);
+    return launch_status();
+}

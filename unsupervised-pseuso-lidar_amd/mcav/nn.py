@@ -1,0 +1,333 @@
+"""Host-side building blocks of the MI355X networks: ctypes mirrors of include/mcav_conv.h and thin op wrappers.
+
+Everything here launches HIP kernels through the C ABI on torch's current stream.  Activations are NHWC fp32
+torch tensors ([B, H, W, C]); parameters keep the reference's shapes (OIHW conv weights) so state_dicts are
+interchangeable, and are re-packed to the kernels' [Np][taps][Kp] form whenever they change.
+"""
+import ctypes
+
+import torch
+
+from . import lib as L
+
+c_p, c_i, c_f, c_sz, c_d = L.c_p, L.c_i, L.c_f, L.c_sz, ctypes.c_double
+
+G_DIRECT, G_SMALLC, G_ADJ_REFLECT, G_ADJ_STRIDE2 = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
+
+
+class IgemmDesc(ctypes.Structure):
+    _fields_ = [("x1", c_p), ("x2", c_p), ("B", c_i), ("Hs", c_i), ("Ws", c_i), ("C1", c_i), ("C2", c_i), ("up1", c_i),
+                ("w", c_p), ("kh", c_i), ("kw", c_i), ("Np", c_i), ("Kp", c_i),
+                ("mode", c_i), ("stride", c_i), ("sign", c_i), ("offset", c_i), ("pad_mode", c_i),
+                ("y", c_p), ("Hd", c_i), ("Wd", c_i), ("Cd", c_i), ("n_begin", c_i), ("n_count", c_i), ("y_choff", c_i),
+                ("bias", c_p), ("act", c_i), ("dact_aux", c_p), ("dact", c_i), ("addend", c_p), ("pool", c_i), ("stats", c_p),
+                ("tile", c_i)]
+
+
+class WgradDesc(ctypes.Structure):
+    _fields_ = [("x1", c_p), ("x2", c_p), ("B", c_i), ("Hs", c_i), ("Ws", c_i), ("C1", c_i), ("C2", c_i), ("up1", c_i),
+                ("kh", c_i), ("kw", c_i), ("Kp", c_i),
+                ("mode", c_i), ("stride", c_i), ("sign", c_i), ("offset", c_i), ("pad_mode", c_i),
+                ("dy", c_p), ("Hd", c_i), ("Wd", c_i), ("Cdy", c_i), ("dy_choff", c_i), ("Cout", c_i), ("Cin", c_i),
+                ("dw_oihw", c_p), ("accumulate", c_i), ("dbias", c_p), ("tile", c_i)]
+
+
+L.register({
+    "mcav_igemm_mtiles": (c_i, [ctypes.POINTER(IgemmDesc)]),
+    "mcav_igemm": (c_i, [ctypes.POINTER(IgemmDesc), c_p]),
+    "mcav_wgrad_workspace_bytes": (c_sz, [ctypes.POINTER(WgradDesc)]),
+    "mcav_wgrad": (c_i, [ctypes.POINTER(WgradDesc), c_p, c_sz, c_p]),
+    "mcav_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "mcav_nchw_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "mcav_nhwc_to_nchw": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "mcav_bn_finalize": (c_i, [c_p, c_i, c_i, c_d, c_p, c_p, c_f, c_f] + [c_p] * 7),
+    "mcav_bn_eval_coeffs": (c_i, [c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p]),
+    "mcav_bn_apply": (c_i, [c_p, c_p, c_p, c_p, c_i, c_sz, c_i, c_p, c_p]),
+    "mcav_bn_bwd_workspace_bytes": (c_sz, [c_sz, c_i]),
+    "mcav_bn_bwd_reduce": (c_i, [c_p] * 5 + [c_i, c_sz, c_i, c_p, c_p, c_i, c_p, c_p, c_sz, c_p]),
+    "mcav_bn_bwd_apply": (c_i, [c_p] * 7 + [c_i, c_sz, c_i, c_p, c_p, c_i, c_p]),
+    "mcav_maxpool3s2_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "mcav_maxpool3s2_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "mcav_act_bwd": (c_i, [c_p, c_p, c_i, c_sz, c_p, c_i, c_p]),
+    "mcav_add": (c_i, [c_p, c_p, c_sz, c_p, c_p]),
+    "mcav_spatial_mean": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
+    "mcav_spatial_mean_bwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
+    "mcav_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_sz, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
+})
+
+
+def up16(v):
+    return (v + 15) // 16 * 16
+
+
+def empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def P(t):
+    return t.data_ptr() if t is not None else None
+
+
+# ------------------------------------------------------------------------------------------------ conv parameters
+class ConvSpec:
+    """Static description of one convolution + the packed copies of its weight (kept fresh lazily)."""
+
+    def __init__(self, weight, bias, stride, pad, pad_mode, smallc=False):
+        self.weight, self.bias = weight, bias           # nn.Parameters, OIHW / [Cout]
+        self.cout, self.cin, self.kh, self.kw = weight.shape
+        self.stride, self.pad, self.pad_mode = stride, pad, pad_mode
+        self.smallc = smallc                             # the 3-channel image stem: source is NHWC4
+        self.kp = 4 if smallc else up16(self.cin)        # K padding of the forward filter
+        self.np = up16(self.cout)
+        self._fwd = self._bwd = None
+        self._key_f = self._key_b = None
+
+    def _key(self):
+        w = self.weight
+        return (w.data_ptr(), w._version, getattr(w, "_mcav_epoch", lambda: 0)())
+
+    def packed_fwd(self):
+        key = self._key()
+        if self._fwd is None or self._key_f != key or self._fwd.device != self.weight.device:
+            taps = self.kh * self.kw
+            kstride = up16(taps * self.kp)
+            if self._fwd is None or self._fwd.device != self.weight.device:
+                self._fwd = empty((self.np, kstride), self.weight)
+            L.check(L.lib().mcav_pack_weights(P(self.weight), self.cout, self.cin, self.kh, self.kw, 0, P(self._fwd), self.np, self.kp,
+                                              L.stream()), "mcav_pack_weights")
+            self._key_f = key
+        return self._fwd
+
+    def packed_bwd(self):
+        """Data-gradient filter: rows = input channels (padded to 16), K = output channels (padded to 16)."""
+        key = self._key()
+        if self._bwd is None or self._key_b != key or self._bwd.device != self.weight.device:
+            taps = self.kh * self.kw
+            npd, kpd = up16(self.cin), up16(self.cout)
+            if self._bwd is None or self._bwd.device != self.weight.device:
+                self._bwd = empty((npd, taps * kpd), self.weight)
+            L.check(L.lib().mcav_pack_weights(P(self.weight), self.cout, self.cin, self.kh, self.kw, 1, P(self._bwd), npd, kpd, L.stream()),
+                    "mcav_pack_weights")
+            self._key_b = key
+        return self._bwd
+
+
+def out_size(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0):
+    """y = act(conv(cat(up2?(x1), x2)) + bias).  x1/x2 NHWC.  Returns y, or (y, stats_slab, mtiles) when stats."""
+    B = x1.shape[0]
+    Hs, Ws = (x1.shape[1] * 2, x1.shape[2] * 2) if up1 else (x1.shape[1], x1.shape[2])
+    C1 = x1.shape[3]
+    C2 = x2.shape[3] if x2 is not None else 0
+    Hd, Wd = out_size(Hs, spec.kh, spec.stride, spec.pad), out_size(Ws, spec.kw, spec.stride, spec.pad)
+    y = empty((B, Hd, Wd, spec.cout), x1)
+    d = IgemmDesc()
+    d.x1, d.x2 = P(x1), P(x2)
+    d.B, d.Hs, d.Ws, d.C1, d.C2, d.up1 = B, Hs, Ws, C1, C2, int(up1)
+    d.w = P(spec.packed_fwd())
+    d.kh, d.kw, d.Np, d.Kp = spec.kh, spec.kw, spec.np, spec.kp
+    d.mode = G_SMALLC if spec.smallc else G_DIRECT
+    d.stride, d.sign, d.offset, d.pad_mode = spec.stride, 1, -spec.pad, spec.pad_mode
+    d.y, d.Hd, d.Wd, d.Cd, d.n_begin, d.n_count, d.y_choff = P(y), Hd, Wd, spec.cout, 0, spec.cout, 0
+    d.bias, d.act = P(spec.bias), act
+    d.tile = tile
+    h = L.lib()
+    slab = None
+    if stats:
+        mt = h.mcav_igemm_mtiles(ctypes.byref(d))
+        if mt <= 0:
+            raise L.MCAVError("mcav_igemm_mtiles: invalid descriptor (%d)" % mt)
+        slab = empty((mt, 2, spec.cout), x1)
+        d.stats = P(slab)
+    L.check(h.mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(fwd)")
+    return (y, slab) if stats else y
+
+
+def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=None, dact=ACT_NONE, addend=None, pool=False, tile=0):
+    """Gradient w.r.t. the (logical, concatenated) conv input, channels [n_begin, n_begin + n_count).
+
+    dy: [B, Hd, Wd, Cout] gradient at the conv output (pre-activation).  in_shape = (Hs, Ws) of the logical input.
+    Epilogue: 2x2 sum pooling (pool), * act'(dact_aux), + addend.  Returns [B, Hs(/2), Ws(/2), n_count]."""
+    B, Hd, Wd, Cout = dy.shape
+    Hs, Ws = in_shape
+    if n_count is None:
+        n_count = spec.cin
+    wb = spec.packed_bwd()
+    y = out if out is not None else empty((B, Hs // 2 if pool else Hs, Ws // 2 if pool else Ws, n_count), dy)
+    d = IgemmDesc()
+    d.x1, d.x2 = P(dy), None
+    d.B, d.Hs, d.Ws, d.C1, d.C2, d.up1 = B, Hd, Wd, Cout, 0, 0
+    d.w = P(wb)
+    d.kh, d.kw, d.Np, d.Kp = spec.kh, spec.kw, up16(spec.cin), up16(spec.cout)
+    if spec.stride == 1:
+        if spec.pad_mode == PAD_REFLECT:
+            d.mode, d.stride, d.sign, d.offset = G_ADJ_REFLECT, 1, -1, 1
+        else:
+            d.mode, d.stride, d.sign, d.offset = G_DIRECT, 1, -1, spec.pad
+    elif spec.stride == 2 and spec.pad_mode == PAD_ZERO:
+        d.mode, d.stride, d.sign, d.offset = G_ADJ_STRIDE2, 2, -1, spec.pad
+    else:
+        raise L.MCAVError("conv_dgrad: unsupported stride/padding combination")
+    d.pad_mode = PAD_ZERO
+    d.y, d.Hd, d.Wd, d.Cd, d.n_begin, d.n_count, d.y_choff = P(y), Hs, Ws, y.shape[3], n_begin, n_count, 0
+    d.bias, d.act = None, ACT_NONE
+    d.dact_aux, d.dact, d.addend, d.pool = P(dact_aux), dact, P(addend), int(pool)
+    d.tile = tile
+    L.check(L.lib().mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(dgrad)")
+    return y
+
+
+def conv_wgrad(spec, x1, dy, x2=None, up1=False, tile=0):
+    """Accumulates d loss / d weight (OIHW) and d loss / d bias into the parameters' .grad buffers."""
+    B = x1.shape[0]
+    Hs, Ws = (x1.shape[1] * 2, x1.shape[2] * 2) if up1 else (x1.shape[1], x1.shape[2])
+    gw = grad_buffer(spec.weight)
+    gb = grad_buffer(spec.bias) if spec.bias is not None else None
+    d = WgradDesc()
+    d.x1, d.x2 = P(x1), P(x2)
+    d.B, d.Hs, d.Ws, d.C1, d.C2, d.up1 = B, Hs, Ws, x1.shape[3], (x2.shape[3] if x2 is not None else 0), int(up1)
+    d.kh, d.kw, d.Kp = spec.kh, spec.kw, spec.kp
+    d.mode = G_SMALLC if spec.smallc else G_DIRECT
+    d.stride, d.sign, d.offset, d.pad_mode = spec.stride, 1, -spec.pad, spec.pad_mode
+    d.dy, d.Hd, d.Wd, d.Cdy, d.dy_choff = P(dy), dy.shape[1], dy.shape[2], dy.shape[3], 0
+    d.Cout, d.Cin = spec.cout, spec.cin
+    d.dw_oihw, d.accumulate, d.dbias = P(gw), 1, P(gb)
+    d.tile = tile
+    h = L.lib()
+    nbytes = h.mcav_wgrad_workspace_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        raise L.MCAVError("mcav_wgrad: invalid descriptor")
+    ws = L.workspace(nbytes, x1.device, "wgrad")
+    L.check(h.mcav_wgrad(ctypes.byref(d), P(ws), ws.numel(), L.stream()), "mcav_wgrad")
+
+
+def grad_buffer(param):
+    """The tensor gradients are accumulated into: param.grad (created zeroed on first use; arena-backed when flattened)."""
+    if param.grad is None:
+        make = getattr(param, "_mcav_grad_view", None)
+        param.grad = make() if make is not None else torch.zeros_like(param)
+    return param.grad
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm
+class BNState:
+    """Per-call saved tensors of one train-mode BatchNorm."""
+    __slots__ = ("scale", "shift", "mean", "invstd")
+
+
+def bn_train_coeffs(bn, slab, count):
+    """bn: holder with weight, bias, running_mean, running_var, num_batches_tracked, eps, momentum."""
+    C = bn.weight.shape[0]
+    st = BNState()
+    buf = empty((4, C), bn.weight)
+    st.scale, st.shift, st.mean, st.invstd = buf[0], buf[1], buf[2], buf[3]
+    L.check(L.lib().mcav_bn_finalize(P(slab), slab.shape[0], C, float(count), P(bn.weight), P(bn.bias), bn.eps, bn.momentum,
+                                     P(bn.running_mean), P(bn.running_var), P(st.scale), P(st.shift), P(st.mean), P(st.invstd), L.stream()),
+            "mcav_bn_finalize")
+    bn.num_batches_tracked += 1
+    return st
+
+
+def bn_eval_coeffs(bn):
+    C = bn.weight.shape[0]
+    st = BNState()
+    buf = empty((2, C), bn.weight)
+    st.scale, st.shift, st.mean, st.invstd = buf[0], buf[1], None, None
+    L.check(L.lib().mcav_bn_eval_coeffs(P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var), bn.eps, C, P(st.scale), P(st.shift),
+                                        L.stream()), "mcav_bn_eval_coeffs")
+    return st
+
+
+def bn_apply(x, st, relu, residual=None):
+    y = torch.empty_like(x)
+    C = x.shape[-1]
+    L.check(L.lib().mcav_bn_apply(P(x), P(st.scale), P(st.shift), P(residual), ACT_RELU if relu else ACT_NONE, x.numel() // C, C, P(y), L.stream()),
+            "mcav_bn_apply")
+    return y
+
+
+def bn_backward(bn, st, dy, y_act, x, relu, want_dres=False, dres_out=None, dres_accumulate=False):
+    """-> dx (and dz, the masked incoming gradient, when want_dres).  Accumulates dgamma/dbeta into .grad."""
+    C = x.shape[-1]
+    n_pix = x.numel() // C
+    h = L.lib()
+    ws = L.workspace(h.mcav_bn_bwd_workspace_bytes(n_pix, C), x.device, "bn_bwd")
+    sums = empty((2, C), x)
+    gg, gb = grad_buffer(bn.weight), grad_buffer(bn.bias)
+    L.check(h.mcav_bn_bwd_reduce(P(dy), P(y_act), P(x), P(st.mean), P(st.invstd), int(relu), n_pix, C, P(gg), P(gb), 1, P(sums), P(ws), ws.numel(),
+                                 L.stream()), "mcav_bn_bwd_reduce")
+    dx = torch.empty_like(x)
+    dres = None
+    if want_dres:
+        dres = dres_out if dres_out is not None else torch.empty_like(x)
+    L.check(h.mcav_bn_bwd_apply(P(dy), P(y_act), P(x), P(bn.weight), P(st.mean), P(st.invstd), P(sums), int(relu), n_pix, C, P(dx), P(dres),
+                                int(dres_accumulate), L.stream()), "mcav_bn_bwd_apply")
+    return (dx, dres) if want_dres else dx
+
+
+# ------------------------------------------------------------------------------------------------ misc ops
+def nchw_to_nhwc(src, Cp, dst=None, choff=0):
+    B, C, H, W = src.shape
+    if dst is None:
+        dst = torch.zeros((B, H, W, Cp), dtype=torch.float32, device=src.device)
+    L.check(L.lib().mcav_nchw_to_nhwc(P(src), B, C, H, W, P(dst), Cp, choff, L.stream()), "mcav_nchw_to_nhwc")
+    return dst
+
+
+def nhwc_to_nchw(src, C=None, choff=0):
+    B, H, W, Cp = src.shape
+    C = Cp if C is None else C
+    dst = empty((B, C, H, W), src)
+    L.check(L.lib().mcav_nhwc_to_nchw(P(src), B, C, H, W, Cp, choff, P(dst), L.stream()), "mcav_nhwc_to_nchw")
+    return dst
+
+
+def maxpool_fwd(x):
+    B, H, W, C = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = empty((B, Ho, Wo, C), x)
+    idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    L.check(L.lib().mcav_maxpool3s2_fwd(P(x), B, H, W, C, P(y), P(idx), L.stream()), "mcav_maxpool3s2_fwd")
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, in_shape, dx=None, accumulate=False):
+    B, H, W, C = in_shape
+    if dx is None:
+        dx = empty(in_shape, dy)
+        accumulate = False
+    L.check(L.lib().mcav_maxpool3s2_bwd(P(dy), P(idx), B, H, W, C, P(dx), int(accumulate), L.stream()), "mcav_maxpool3s2_bwd")
+    return dx
+
+
+def act_bwd(dy, y, act, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty_like(y)
+        accumulate = False
+    L.check(L.lib().mcav_act_bwd(P(dy), P(y), act, y.numel(), P(out), int(accumulate), L.stream()), "mcav_act_bwd")
+    return out
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    L.check(L.lib().mcav_add(P(a), P(b), a.numel(), P(out), L.stream()), "mcav_add")
+    return out
+
+
+def spatial_mean(x, scale):
+    B, H, W, C = x.shape
+    out = empty((B, C), x)
+    L.check(L.lib().mcav_spatial_mean(P(x), B, H * W, C, scale, P(out), L.stream()), "mcav_spatial_mean")
+    return out
+
+
+def spatial_mean_bwd(dout, shape, scale):
+    B, H, W, C = shape
+    dx = empty(shape, dout)
+    L.check(L.lib().mcav_spatial_mean_bwd(P(dout), B, H * W, C, scale, P(dx), L.stream()), "mcav_spatial_mean_bwd")
+    return dx

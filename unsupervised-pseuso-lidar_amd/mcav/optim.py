@@ -1,0 +1,44 @@
+"""Fused Adam over the flat arena (replaces optim.Adam at reference trainer.py:75; defaults as torch.optim.Adam)."""
+import torch
+
+from . import lib as L
+from . import nn as N
+from .arena import arena_of
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._arena = None
+        self._m = self._v = None
+        self._step = 0
+        self._step_t = torch.zeros(())          # shared by every state entry (torch.optim.Adam keeps one per parameter)
+        self.grad_scale = 1.0          # 1/world_size under data parallelism (gradients are summed by the all-reduce)
+
+    def arena(self):
+        params = [p for g in self.param_groups for p in g["params"]]
+        if self._arena is None or not self._arena.intact():
+            self._arena = arena_of(params)
+            self._m = torch.zeros_like(self._arena.flat)
+            self._v = torch.zeros_like(self._arena.flat)
+            for p, o in zip(self._arena.params, self._arena.offsets):
+                n = p.numel()
+                self.state[p] = {"step": self._step_t, "exp_avg": self._m[o:o + n].view(p.shape),
+                                 "exp_avg_sq": self._v[o:o + n].view(p.shape)}
+        return self._arena
+
+    def zero_grad(self, set_to_none=False):
+        a = self.arena()
+        a.attach_grads()
+        a.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        a = self.arena()
+        g = self.param_groups[0]
+        self._step += 1
+        b1, b2 = g["betas"]
+        L.check(L.lib().mcav_adam_step(N.P(a.flat), N.P(a.gflat), N.P(self._m), N.P(self._v), a.numel, g["lr"], b1, b2, g["eps"], self._step,
+                                       self.grad_scale, L.stream()), "mcav_adam_step")
+        a.bump()
+        self._step_t.fill_(float(self._step))

@@ -1,0 +1,44 @@
+"""models/depth/layers.py -- the reference's decoder building blocks (models/depth/layers.py:22-58) as parameter holders.
+
+ConvBlock = reflection-padded 3x3 conv + ELU, Conv3x3 = reflection-padded 3x3 conv.  The modules own the parameters
+under the reference's attribute names (`.conv.conv.weight`, `.conv.weight`); standalone calls run the HIP conv kernel.
+"""
+import torch.nn as nn
+
+from mcav import nn as N
+from mcav.holders import ConvParams
+from mcav.depthnet import dec_spec
+
+
+def disp_to_depth(disp, min_depth, max_depth):
+    """scaled_disp, depth as monodepth2's helper (reference layers.py:10-19; unused on the hot path). Forward only."""
+    min_disp = 1 / max_depth
+    max_disp = 1 / min_depth
+    scaled_disp = min_disp + (max_disp - min_disp) * disp
+    return scaled_disp, 1 / scaled_disp
+
+
+class Conv3x3(nn.Module):
+    def __init__(self, in_channels, out_channels, use_refl=True):
+        super().__init__()
+        if not use_refl:
+            raise NotImplementedError("only the reflection-padded variant (the reference's only use) is built")
+        self.conv = ConvParams(int(in_channels), int(out_channels), 3)
+
+    def forward(self, x):
+        """x NCHW -> NCHW (forward only; the differentiable path is DepthDecoder / DispResNet)."""
+        return N.nhwc_to_nchw(N.conv_fwd(dec_spec(self.conv), N.nchw_to_nhwc(x, N.up16(x.shape[1]) if x.shape[1] % 4 else x.shape[1])))
+
+
+class ConvBlock(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = Conv3x3(in_channels, out_channels)
+
+    def forward(self, x):
+        xin = N.nchw_to_nhwc(x, x.shape[1])
+        return N.nhwc_to_nchw(N.conv_fwd(dec_spec(self.conv.conv), xin, act=N.ACT_ELU))
+
+
+def upsample(x):
+    raise NotImplementedError("nearest x2 upsampling is fused into the decoder's conv gather (mcav/depthnet.py)")

@@ -1,0 +1,176 @@
+"""models/depth/resnet_dispnet.py -- drop-in for the reference module (models/depth/resnet_dispnet.py:12-107) on MI355X.
+
+ResnetEncoder (torchvision resnet18/34 trunk restated with torchvision's parameter names), DepthDecoder (monodepth2
+decoder, positional ModuleList keys 0..13 as the reference registers them) and DispResNet (no-arg constructor,
+`__call__(img[B,3,H,W]) -> [disp[B,1,H,W]]`).  Parameters have the reference's names and shapes; the arithmetic is
+the HIP engine in mcav/depthnet.py.  `pretrained=True` cannot fetch ImageNet weights offline: weights are torchvision's
+random init (kaiming_normal fan_out) until a state_dict is loaded.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from mcav import lib as L
+from mcav import nn as N
+from mcav import depthnet as E
+from mcav.holders import BNParams, ConvParams, LinearParams
+from .layers import ConvBlock, Conv3x3
+
+BLOCK_COUNTS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = ConvParams(inplanes, planes, 3, bias=False)
+        self.bn1 = BNParams(planes)
+        self.conv2 = ConvParams(planes, planes, 3, bias=False)
+        self.bn2 = BNParams(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class ResNet(nn.Module):
+    """torchvision.models.resnet{18,34} parameter layout (conv1, bn1, layer1-4, fc)."""
+
+    def __init__(self, num_layers=18):
+        super().__init__()
+        if num_layers not in BLOCK_COUNTS:
+            raise ValueError("ResNet-%s is not built yet (BasicBlock nets 18/34 only)" % num_layers)
+        self.conv1 = ConvParams(3, 64, 7, bias=False)
+        self.bn1 = BNParams(64)
+        inplanes = 64
+        for si, (planes, n) in enumerate(zip((64, 128, 256, 512), BLOCK_COUNTS[num_layers])):
+            blocks = []
+            for bi in range(n):
+                stride = 2 if (si > 0 and bi == 0) else 1
+                ds = None
+                if stride != 1 or inplanes != planes:
+                    ds = nn.Sequential(ConvParams(inplanes, planes, 1, bias=False), BNParams(planes))
+                blocks.append(BasicBlock(inplanes, planes, stride, ds))
+                inplanes = planes
+            setattr(self, "layer%d" % (si + 1), nn.Sequential(*blocks))
+        self.fc = LinearParams(512, 1000)          # unused by the depth net; kept for state_dict compatibility
+        for m in self.modules():
+            if isinstance(m, ConvParams):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+
+def _to_nhwc4(x):
+    x = L.dev(x.contiguous(), "image")
+    if x.shape[1] != 3:
+        raise L.MCAVError("expected a 3-channel image batch [B,3,H,W]")
+    return N.nchw_to_nhwc(x, 4)
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, *params):
+        feats, sv = E.encoder_forward(mod.encoder, _to_nhwc4(x), mod.training)
+        ctx.mod, ctx.sv = mod, sv
+        return tuple(N.nhwc_to_nchw(f) for f in feats)
+
+    @staticmethod
+    def backward(ctx, *gfeats):
+        dfe = [N.nchw_to_nhwc(L.dev(g.contiguous(), "grad"), g.shape[1]) for g in gfeats]
+        E.encoder_backward(ctx.mod.encoder, ctx.sv, dfe)
+        return (None, None) + (None,) * len(list(ctx.mod.parameters()))
+
+
+class ResnetEncoder(nn.Module):
+    def __init__(self, num_layers=18, pretrained=False):
+        super().__init__()
+        self.num_ch_enc = np.array([64, 64, 128, 256, 512])
+        self.encoder = ResNet(num_layers)
+
+    def forward(self, x):
+        """img [B,3,H,W] -> 5 feature maps (NCHW), differentiable w.r.t. the parameters."""
+        self.features = list(_EncoderFn.apply(x, self, *self.parameters()))
+        return self.features
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, nparams, *args):
+        feats_nchw = args[nparams:]
+        feats = [N.nchw_to_nhwc(L.dev(f.contiguous(), "feature"), f.shape[1]) for f in feats_nchw]
+        disps, sv = E.decoder_forward(mod, feats, mod.scales)
+        ctx.mod, ctx.sv, ctx.nparams = mod, sv, nparams
+        return tuple(disps[s].view(disps[s].shape[0], 1, disps[s].shape[1], disps[s].shape[2]) for s in mod.scales)
+
+    @staticmethod
+    def backward(ctx, *gd):
+        mod = ctx.mod
+        dd = {}
+        for s, g in zip(mod.scales, gd):
+            if g is not None:
+                g = L.dev(g.contiguous(), "grad")
+                dd[s] = g.view(g.shape[0], g.shape[2], g.shape[3], 1)
+        dfe = E.decoder_backward(mod, ctx.sv, dd)
+        return (None, None) + (None,) * ctx.nparams + tuple(N.nhwc_to_nchw(d) for d in dfe)
+
+
+class DepthDecoder(nn.Module):
+    def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
+        super().__init__()
+        if num_output_channels != 1 or not use_skips:
+            raise NotImplementedError("DepthDecoder: the reference's configuration (1 output channel, skips) only")
+        self.scales = list(scales)
+        self.num_ch_enc = np.array(num_ch_enc)
+        self.num_ch_dec = np.array([16, 32, 64, 128, 256])
+        self.index = {}
+        mods = []
+        for i in range(4, -1, -1):
+            cin = self.num_ch_enc[-1] if i == 4 else self.num_ch_dec[i + 1]
+            self.index[("upconv", i, 0)] = len(mods)
+            mods.append(ConvBlock(cin, self.num_ch_dec[i]))
+            cin = self.num_ch_dec[i] + (self.num_ch_enc[i - 1] if i > 0 else 0)
+            self.index[("upconv", i, 1)] = len(mods)
+            mods.append(ConvBlock(cin, self.num_ch_dec[i]))
+        for s in range(4) if set(self.scales) <= set(range(4)) else self.scales:
+            self.index[("dispconv", s)] = len(mods)
+            mods.append(Conv3x3(self.num_ch_dec[s], 1))
+        self.decoder = nn.ModuleList(mods)
+
+    def conv(self, *key):
+        return self.decoder[self.index[key]]
+
+    def forward(self, input_features):
+        """5 NCHW feature maps -> {("disp", s): [B,1,h,w]} for s in self.scales (differentiable: features and parameters)."""
+        params = list(self.parameters())
+        outs = _DecoderFn.apply(self, len(params), *params, *input_features)
+        self.outputs = {("disp", s): o for s, o in zip(self.scales, outs)}
+        return self.outputs
+
+
+class _DispResNetFn(torch.autograd.Function):
+    """Whole depth net as one autograd node: image -> disparity (scale 0)."""
+
+    @staticmethod
+    def forward(ctx, x, mod, *params):
+        feats, esv = E.encoder_forward(mod.encoder.encoder, _to_nhwc4(x), mod.training)
+        disps, dsv = E.decoder_forward(mod.decoder, feats, (0,))
+        ctx.mod, ctx.esv, ctx.dsv = mod, esv, dsv
+        d = disps[0]
+        return d.view(d.shape[0], 1, d.shape[1], d.shape[2])       # NHWC with C = 1 is NCHW
+
+    @staticmethod
+    def backward(ctx, g):
+        mod = ctx.mod
+        g = L.dev(g.contiguous(), "grad")
+        dfe = E.decoder_backward(mod.decoder, ctx.dsv, {0: g.view(g.shape[0], g.shape[2], g.shape[3], 1)})
+        E.encoder_backward(mod.encoder.encoder, ctx.esv, dfe)
+        ctx.esv = ctx.dsv = None
+        return (None, None) + (None,) * len(list(mod.parameters()))
+
+
+class DispResNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.encoder = ResnetEncoder(18, True)
+        self.decoder = DepthDecoder(self.encoder.num_ch_enc)
+
+    def forward(self, x):
+        return [_DispResNetFn.apply(x, self, *self.parameters())]

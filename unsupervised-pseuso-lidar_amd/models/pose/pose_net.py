@@ -1,0 +1,58 @@
+"""models/pose/pose_net.py -- drop-in for the reference PoseNet (models/pose/pose_net.py:31-77) on MI355X.
+
+Same constructor, `init_weights()` (xavier_uniform + zero bias) and `__call__(tgt, [ref0, ref1]) -> [B,2,6]`
+(axis-angle, translation); parameters named convN.0.weight/bias and pose_pred.weight/bias as in the reference.
+"""
+import torch
+import torch.nn as nn
+
+from mcav import lib as L
+from mcav import posenet as E
+from mcav.holders import ConvParams
+
+
+def conv_gn(in_planes, out_planes, kernel_size=3):
+    """Reference helper name kept: conv(stride 2) + ReLU (its GroupNorm is commented out, pose_net.py:27)."""
+    return nn.Sequential(ConvParams(in_planes, out_planes, kernel_size))
+
+
+class _PoseNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, tgt, ref0, ref1, *params):
+        imgs = [L.dev(t.contiguous(), "image") for t in (tgt, ref0, ref1)]
+        out, saved = E.forward(mod, imgs[0], imgs[1:])
+        ctx.mod, ctx.saved = mod, saved
+        return out.view(out.shape[0], mod.nb_ref_imgs, 6)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = L.dev(g.contiguous(), "grad")
+        E.backward(ctx.mod, ctx.saved, g.view(g.shape[0], -1))
+        ctx.saved = None
+        return (None,) * (4 + len(list(ctx.mod.parameters())))
+
+
+class PoseNet(nn.Module):
+    def __init__(self, nb_ref_imgs=2, rotation_mode='euler', **kwargs):
+        super().__init__()
+        if nb_ref_imgs != 2:
+            raise NotImplementedError("PoseNet: two reference images (the reference's configuration) only")
+        self.nb_ref_imgs = nb_ref_imgs
+        self.rotation_mode = rotation_mode
+        ch = [16, 32, 64, 128, 256, 256, 256]
+        cin = 3 * (1 + nb_ref_imgs)
+        for i, (c, k) in enumerate(zip(ch, E.KS)):
+            setattr(self, "conv%d" % (i + 1), conv_gn(cin, c, k))
+            cin = c
+        self.pose_pred = ConvParams(cin, 6 * nb_ref_imgs, 1)
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, ConvParams):
+                nn.init.xavier_uniform_(m.weight.data)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+    def forward(self, image, context):
+        assert len(context) == self.nb_ref_imgs
+        return _PoseNetFn.apply(self, image, context[0], context[1], *self.parameters())
