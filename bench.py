@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X: triplets ("images")/sec through one full training step.
+
+One step = trainer.py:261-266 + :290-313 of the reference: zero_grad, 2 x DispResNet forward (tgt, ref0), PoseNet
+forward, fused warp/L1/smoothness loss, backward through everything, (gradient all-reduce when N > 1), Adam.
+Workload at N=1: BASELINE.json configs[1] -- batch 12, 192x640 KITTI-shaped triplets, ResNet-18 depth encoder +
+6-DoF PoseNet, fp32.  Synthetic seeded inputs resident in HBM before the timed region; random-init weights.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     conv stage (igemm + wgrad MFMA kernels): algorithmic FLOPs / summed kernel time, measured with HIP events
+               on the launch stream in a separate instrumented step after the timed region (never part of `value`)
+  cpu_baseline the CPU oracle (oracle/, stock PyTorch ops) timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "unsupervised-pseuso-lidar_amd")
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+# conv FLOPs fwd per triplet at 192x640 R18 = 2 x 16.03 + 0.89 GF; fwd + dgrad + wgrad = 3x
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_samples(B, H, W, rank, step=0):
+    from oracle.step import synthetic_batch       # input generator only (shared with the tests)
+    return synthetic_batch(B, H, W, seed=1234 + 1000 * rank + step)
+
+
+def build(device, lr=1e-4, seed=0):
+    from models.depth.resnet_dispnet import DispResNet
+    from models.pose.pose_net import PoseNet
+    from mcav.optim import FusedAdam
+    from losses import Losses
+    torch.manual_seed(seed)
+    depth = DispResNet()
+    pose = PoseNet()
+    pose.init_weights()
+    depth.to(device).train()
+    pose.to(device).train()
+    opt = FusedAdam(list(depth.parameters()) + list(pose.parameters()), lr)
+    return depth, pose, opt, Losses()
+
+
+def make_step(depth, pose, opt, crit, samples):
+    from mcav import dist as mdist
+    tgt, refs, K = samples["tgt"], samples["ref_imgs"], samples["intrinsics"]
+
+    def step():
+        opt.zero_grad()
+        disps = [depth(tgt), depth(refs[0])]
+        poses = pose(tgt, refs)
+        loss = crit.forward(tgt, refs, disps, poses, K, None)
+        sum(loss).backward()
+        opt.grad_scale = mdist.allreduce_gradients(opt.arena())
+        opt.step()
+        return loss
+    return step
+
+
+def cpu_baseline(B, H, W, steps=2):
+    """The CPU oracle's full step (stock PyTorch ops) on the host cores; bounded sample."""
+    from oracle import nets as onets
+    from oracle.step import make_optimizer, synthetic_batch, train_step
+    torch.manual_seed(0)
+    depth, pose = onets.DispResNet(), onets.PoseNet()
+    pose.init_weights()
+    depth.train()
+    pose.train()
+    opt = make_optimizer(depth, pose, 1e-4)
+    s = synthetic_batch(B, H, W, seed=1234)
+    train_step(depth, pose, opt, s)                      # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        train_step(depth, pose, opt, s)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(B / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d full steps (after 1 warm-up) of the same batch=%d %dx%d ResNet-18+PoseNet fp32 workload, oracle/ in stock PyTorch "
+                      "CPU ops, %.2f s/step, os.cpu_count()=%d" % (steps, B, H, W, dt, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from mcav import dist as mdist
+    from mcav import nn as N
+    rank, world = mdist.init_from_env("nccl")
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(device)
+    B, H, W = args.batch, args.height, args.width
+
+    depth, pose, opt, crit = build(device)
+    mdist.broadcast_parameters(opt.arena())
+    s = synthetic_samples(B, H, W, rank)
+    samples = {"tgt": s["tgt"].to(device), "ref_imgs": [r.to(device) for r in s["ref_imgs"]], "intrinsics": s["intrinsics"].to(device)}
+    step = make_step(depth, pose, opt, crit, samples)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1000.0 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+
+    out = {"metric": "images/sec (fwd+bwd) KITTI 192x640 triplets, full training step", "value": round(value, 3), "unit": "images/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE.json configs[1]: per-GPU batch=%d, %dx%d KITTI-shaped triplets, ResNet-18 depth encoder + 6-DoF PoseNet, "
+                                  "fp32, one step = 2x depth fwd + pose fwd + warp/L1/smooth loss + backward + Adam%s" %
+                                  (B, H, W, " + 1 RCCL all-reduce of the 63.7 MB gradient arena" if world > 1 else ""),
+                      "global_batch": B * world, "parallelism": "dp%d" % world},
+           "loss": [round(float(l), 6) for l in loss]}
+
+    if rank == 0 and not args.no_roofline:
+        # instrumented step(s): every conv launch bracketed by events on the launch stream
+        N.PROFILE = []
+        N.PROFILE_LOSS = []
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        recs, N.PROFILE = N.PROFILE, None
+        lrecs, N.PROFILE_LOSS = N.PROFILE_LOSS, None
+        ms = sum(e0.elapsed_time(e1) for (_, _, e0, e1) in recs) / 3.0
+        flops = sum(f for (_, f, _, _) in recs) / 3.0
+        by_kind = {}
+        for kind, f, e0, e1 in recs:
+            a = by_kind.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += f / 3.0
+            a[1] += e0.elapsed_time(e1) / 3.0
+            a[2] += 1
+        ach = flops / (ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "kernel": "conv stage = igemm_kernel (fwd+dgrad) + wgrad_kernel, all launches of one step",
+                           "launches_per_step": len(recs) // 3, "algorithmic_gflop_per_step": round(flops / 1e9, 2),
+                           "kernel_ms_per_step": round(ms, 3),
+                           "by_kind": {k: {"gflop": round(v[0] / 1e9, 2), "ms": round(v[1], 3), "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2),
+                                           "launches": v[2] // 3} for k, v in by_kind.items()}}
+        if lrecs:
+            lms = sum(e0.elapsed_time(e1) for (_, e0, e1) in lrecs) / len(lrecs)
+            lbytes = 52.0 * B * H * W
+            out["roofline_warp"] = {"bound": "hbm", "achieved": round(lbytes / (lms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": round(lbytes / (lms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                                    "kernel": "warp_loss_kernel (+prepare/finalize), 52 B/pixel x %d pixels" % (B * H * W), "ms": round(lms, 4)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(B, H, W)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

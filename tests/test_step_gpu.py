@@ -1,0 +1,118 @@
+"""GPU: one full training step (trainer.py:261-266 + 290-313) of the HIP path against the CPU oracle's step."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from seeding import reinit_by_name
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build_pair(seed_d=141, seed_p=121):
+    from models.depth.resnet_dispnet import DispResNet
+    from models.pose.pose_net import PoseNet
+    from oracle import nets as on
+    hip_d, hip_p = reinit_by_name(DispResNet(), seed_d), reinit_by_name(PoseNet(), seed_p)
+    ref_d, ref_p = on.DispResNet(), on.PoseNet()
+    ref_d.load_state_dict(hip_d.state_dict())        # same names and shapes: the state_dict is interchangeable
+    ref_p.load_state_dict(hip_p.state_dict())
+    with torch.no_grad():                            # small pose outputs, as a trained/initialised PoseNet gives
+        for m in (hip_p, ref_p):
+            m.pose_pred.weight.mul_(0.1)
+            m.pose_pred.bias.mul_(0.1)
+    return hip_d.to(DEV).train(), hip_p.to(DEV).train(), ref_d.train(), ref_p.train()
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 128), (3, 96, 160)])
+def test_train_step_vs_oracle(B, H, W):
+    from losses import Losses
+    from mcav.optim import FusedAdam
+    from oracle.step import make_optimizer, synthetic_batch, train_step
+    hip_d, hip_p, ref_d, ref_p = build_pair()
+    s = synthetic_batch(B, H, W, seed=5)
+    ropt = make_optimizer(ref_d, ref_p, 1e-4)
+    (rdisps, rposes), rloss = train_step(ref_d, ref_p, ropt, s)
+
+    opt = FusedAdam(list(hip_d.parameters()) + list(hip_p.parameters()), 1e-4)
+    tgt, refs, K = s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], s["intrinsics"].to(DEV)
+    opt.zero_grad()
+    disps = [hip_d(tgt), hip_d(refs[0])]
+    poses = hip_p(tgt, refs)
+    loss = Losses().forward(tgt, refs, disps, poses, K, None)
+    sum(loss).backward()
+    # forward parity: depth maps within 1e-3 relative (north_star), AbsRel reported
+    for got, want in zip(disps, rdisps):
+        dg, dw = 1 / (10 * got[0].detach().cpu() + 0.01), 1 / (10 * want[0].detach() + 0.01)
+        assert float(((dg - dw).abs() / dw).max()) < 1e-3
+        assert float(((dg - dw).abs() / dw).mean()) < 1e-4
+    assert rel_err(poses, rposes) < 1e-3
+    assert abs(float(loss[0]) - float(rloss[0])) < 1e-3 * abs(float(rloss[0]))
+    assert abs(float(loss[1]) - float(rloss[1])) < 1e-3 * abs(float(rloss[1]))
+    # backward parity on every parameter that receives a gradient (L2-relative: L1/ReLU/max-pool kinks flip a few units)
+    worst = 0.0
+    for (n, p), (_, q) in zip(list(hip_d.named_parameters()) + list(hip_p.named_parameters()),
+                              list(ref_d.named_parameters()) + list(ref_p.named_parameters())):
+        if q.grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        e = float((p.grad.cpu() - q.grad).norm() / q.grad.norm().clamp_min(1e-20))
+        worst = max(worst, e)
+        assert e < 2e-2, (n, e)
+    # optimiser parity after the update
+    opt.step()
+    torch.cuda.synchronize()
+    for (n, p), (_, q) in zip(list(hip_d.named_parameters()) + list(hip_p.named_parameters()),
+                              list(ref_d.named_parameters()) + list(ref_p.named_parameters())):
+        assert float((p.detach().cpu() - q.detach()).abs().max()) <= 2.05e-4, n        # |Adam step| <= lr; sign flips of tiny grads allowed
+    moved = sum(float((p.detach().cpu() - q.detach()).abs().mean()) for (_, p), (_, q) in zip(hip_p.named_parameters(), ref_p.named_parameters()))
+    assert moved < 1e-4
+    # BatchNorm running statistics were updated twice (two depth passes), in order
+    assert int(hip_d.encoder.encoder.bn1.num_batches_tracked) == 2
+    assert rel_err(hip_d.encoder.encoder.bn1.running_var, ref_d.encoder.encoder.bn1.running_var) < 1e-4
+
+
+def test_second_step_uses_updated_weights():
+    """Packed weight copies must follow the fused Adam update (arena epoch), and a state_dict round trip must hold."""
+    from losses import Losses
+    from mcav.optim import FusedAdam
+    from oracle.step import synthetic_batch
+    hip_d, hip_p, _, _ = build_pair()
+    s = synthetic_batch(2, 64, 128, seed=6)
+    tgt, refs, K = s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], s["intrinsics"].to(DEV)
+    opt = FusedAdam(list(hip_d.parameters()) + list(hip_p.parameters()), 1e-3)
+    outs = []
+    for _ in range(2):
+        opt.zero_grad()
+        disps = [hip_d(tgt), hip_d(refs[0])]
+        loss = Losses().forward(tgt, refs, disps, hip_p(tgt, refs), K, None)
+        sum(loss).backward()
+        opt.step()
+        outs.append(disps[0][0].detach().clone())
+    assert float((outs[0] - outs[1]).abs().max()) > 1e-5
+    sd = {k: v.clone() for k, v in hip_d.state_dict().items()}
+    from models.depth.resnet_dispnet import DispResNet
+    fresh = DispResNet().to(DEV).train()
+    fresh.load_state_dict(sd)
+    hip_d.eval()
+    fresh.eval()
+    with torch.no_grad():
+        a, b = hip_d(tgt)[0], fresh(tgt)[0]
+    assert float((a - b).abs().max()) == 0.0
+
+
+def test_trainer_runs_synthetic_epoch():
+    import yaml
+    import os
+    from conftest import PKG
+    from trainer import Trainer
+    cfg = yaml.full_load(open(os.path.join(PKG, "configs", "basic_config.yaml")))
+    cfg["datasets"]["augmentation"].update(image_width=128, image_height=64)
+    cfg["datasets"]["synthetic_length"] = 10
+    cfg["action"].update(batch_size=2, verbose=False, save_checkpoints=False)
+    t = Trainer(cfg)
+    t.train()
+    assert t.step == 4 and torch.isfinite(sum(t.loss)).item()

@@ -342,6 +342,8 @@ __global__ void disp_to_depth_bwd_kernel(const float* disp, const float* dD, flo
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 __global__ __launch_bounds__(256) void ssim_kernel(const float* xs, const float* ys, int N, int H, int W, float C1, float C2, float* out) {
+    // no fma contraction in this kernel: SSIM(x, x) must cancel exactly (num == den), as it does in the reference
+#pragma clang fp contract(off)
     const int n = blockIdx.z;
     const int x = blockIdx.x * TW + (threadIdx.x & 31), y = blockIdx.y * TH + (threadIdx.x >> 5);
     if (x >= W || y >= H) return;

@@ -58,6 +58,29 @@ L.register({
 })
 
 
+# bench.py's instrumented step: when PROFILE is a list every conv launch is bracketed by events on the launch stream
+PROFILE = None
+PROFILE_LOSS = None
+
+
+class _Timed:
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+        return False
+
+
 def up16(v):
     return (v + 15) // 16 * 16
 
@@ -144,7 +167,8 @@ def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0):
             raise L.MCAVError("mcav_igemm_mtiles: invalid descriptor (%d)" % mt)
         slab = empty((mt, 2, spec.cout), x1)
         d.stats = P(slab)
-    L.check(h.mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(fwd)")
+    with _Timed("fwd", 2.0 * B * Hd * Wd * spec.cout * spec.cin * spec.kh * spec.kw):
+        L.check(h.mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(fwd)")
     return (y, slab) if stats else y
 
 
@@ -178,7 +202,8 @@ def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=N
     d.bias, d.act = None, ACT_NONE
     d.dact_aux, d.dact, d.addend, d.pool = P(dact_aux), dact, P(addend), int(pool)
     d.tile = tile
-    L.check(L.lib().mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(dgrad)")
+    with _Timed("dgrad", 2.0 * B * Hd * Wd * Cout * n_count * spec.kh * spec.kw):
+        L.check(L.lib().mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(dgrad)")
     return y
 
 
@@ -203,7 +228,8 @@ def conv_wgrad(spec, x1, dy, x2=None, up1=False, tile=0):
     if nbytes == 0:
         raise L.MCAVError("mcav_wgrad: invalid descriptor")
     ws = L.workspace(nbytes, x1.device, "wgrad")
-    L.check(h.mcav_wgrad(ctypes.byref(d), P(ws), ws.numel(), L.stream()), "mcav_wgrad")
+    with _Timed("wgrad", 2.0 * B * dy.shape[1] * dy.shape[2] * spec.cout * spec.cin * spec.kh * spec.kw):
+        L.check(h.mcav_wgrad(ctypes.byref(d), P(ws), ws.numel(), L.stream()), "mcav_wgrad")
 
 
 def grad_buffer(param):

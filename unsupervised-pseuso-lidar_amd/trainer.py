@@ -1,0 +1,181 @@
+"""trainer.py -- drop-in for the reference Trainer (trainer.py:40-337) driving the MI355X-native step.
+
+Kept: `Trainer(config)` with the reference's YAML schema (configs/basic_config.yaml), dynamic model lookup
+(`models.<type>.<file>.<name>`, trainer.py:154-170), one Adam over depth+pose parameters at optimizer.depth.lr,
+StepLR, checkpoint dict keys (trainer.py:129-152), `train()`, `run_epoch()`, `process_batch(samples)`.
+Changed underneath: the optimiser is the fused Adam over the flat arena, `zero_grad` is one memset, and when
+torch.distributed is initialised the gradient arena is all-reduced once per step (RCCL over xGMI).
+wandb logging and the image dumps are out of scope.
+"""
+import importlib
+import os
+import time
+from inspect import getmembers, isclass
+
+import numpy as np
+import torch
+from torch.utils.data import Sampler
+
+from losses import Losses
+from geometry.pose_geometry import *  # noqa: F401,F403  (the reference star-imports it, trainer.py:27)
+from mcav import dist as mdist
+from mcav.optim import FusedAdam
+
+
+class SequentialIndicesSampler(Sampler):
+    def __init__(self, indices):
+        self.indices = indices
+
+    def __iter__(self):
+        return iter(self.indices)
+
+    def __len__(self):
+        return len(self.indices)
+
+
+class Trainer:
+    def __init__(self, config, dataset=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("Trainer: the MI355X path needs a GPU (there is no CPU fallback)")
+        self.rank, self.world = mdist.init_from_env()
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self.save_path = './pretrained/' + config['model']['name'] + '.pth'
+        act = config['action']
+        self.batch_size = act['batch_size']
+        self.learning_rate = act['optimizer']['depth']['lr']
+        self.scheduler_step_size = act['scheduler']['step_size']
+        self.gamma = act['scheduler']['gamma']
+        self.shuffle_dataset = config['datasets']['augmentation']['shuffle']
+        self.mode = act['mode']
+        self.train_from_scratch = act['from_scratch']
+        self.num_epochs = act['num_epochs']
+        self.num_workers = act['num_workers']
+        self.log_freq = act['log_freq']
+        self.epoch = 0
+        self.step = 0
+        self.verbose = bool(act.get('verbose', True))
+
+        self.depth_model = self.load_from_config(config, model_type='depth')
+        self.pose_model = self.load_from_config(config, model_type='pose')
+        parameters_train = list(self.depth_model.parameters()) + list(self.pose_model.parameters())
+        self.model_optimizer = FusedAdam(parameters_train, self.learning_rate)
+        self.model_lr_scheduler = torch.optim.lr_scheduler.StepLR(self.model_optimizer, self.scheduler_step_size, self.gamma)
+        mdist.broadcast_parameters(self.model_optimizer.arena())
+
+        self.criterion = Losses()
+        self.loss = None
+        self.valid_acc = 0
+        if self.train_from_scratch:
+            if self.rank == 0 and act.get('save_checkpoints', True):
+                self.save_chkpnt()
+        else:
+            self.load_chkpnt()
+
+        if dataset is None:
+            from dataloaders import UnSupKittiDataset
+            dataset = UnSupKittiDataset(config, transforms=None)
+        self.dataset = dataset
+        self.train_loader, self.validation_loader = self.create_loaders(act['random_seed'], act['split'][1])
+        self.save_checkpoints = act.get('save_checkpoints', True)
+
+    # ------------------------------------------------------------------ checkpoints (reference trainer.py:129-152)
+    def save_chkpnt(self):
+        os.makedirs(os.path.dirname(self.save_path), exist_ok=True)
+        self.checkpoint = {'epoch': self.epoch, 'dpth_mdl_state_dict': self.depth_model.state_dict(),
+                           'pose_mdl_state_dict': self.pose_model.state_dict(),
+                           'optimizer_state_dict': self.model_optimizer.state_dict(), 'loss': self.loss, 'valid_acc': self.valid_acc}
+        torch.save(self.checkpoint, self.save_path)
+
+    def load_chkpnt(self):
+        self.checkpoint = torch.load(self.save_path, map_location=self.device)
+        self.depth_model.load_state_dict(self.checkpoint['dpth_mdl_state_dict'])
+        self.pose_model.load_state_dict(self.checkpoint['pose_mdl_state_dict'])
+        self.epoch = self.checkpoint['epoch']
+        self.valid_acc = self.checkpoint['valid_acc']
+
+    def load_from_config(self, config, model_type='depth'):
+        module = importlib.import_module('models.' + model_type + '.' + config['model'][model_type]['file'])
+        model_name = config['model'][model_type]['name']
+        model = None
+        for name, obj in getmembers(module, isclass):
+            if name == model_name:
+                model = obj
+        if model is None:
+            raise ValueError("config: no class %s in models.%s.%s" % (model_name, model_type, config['model'][model_type]['file']))
+        model = model()
+        if self.train_from_scratch and model_type != 'depth':
+            model.init_weights()
+        return model.to(self.device)
+
+    def create_loaders(self, random_seed, valid_split_ratio):
+        indices = list(range(len(self.dataset)))
+        split = int(np.floor(valid_split_ratio * len(indices)))
+        if self.shuffle_dataset:
+            np.random.seed(random_seed)
+            np.random.shuffle(indices)
+        train_indices, val_indices = indices[split:], indices[:split]
+        train_indices = mdist.shard_indices(train_indices, self.rank, self.world)      # data parallel: disjoint slices
+        mk = lambda idx: torch.utils.data.DataLoader(self.dataset, batch_size=self.batch_size, sampler=SequentialIndicesSampler(idx),
+                                                     num_workers=self.num_workers, drop_last=True, pin_memory=True)
+        return mk(train_indices), mk(val_indices)
+
+    def set_train(self):
+        self.depth_model.train()
+        self.pose_model.train()
+
+    def set_eval(self):
+        self.depth_model.eval()
+        self.pose_model.eval()
+
+    # ------------------------------------------------------------------ the hot loop (reference trainer.py:242-313)
+    def train(self):
+        self.set_train()
+        self.start_time = time.time()
+        for self.epoch in range(self.num_epochs):
+            self.run_epoch()
+
+    def train_step(self, samples):
+        """zero_grad -> process_batch -> backward -> (all-reduce) -> Adam  (reference trainer.py:261-266)."""
+        self.model_optimizer.zero_grad()
+        outputs, self.loss = self.process_batch(samples)
+        sum(self.loss).backward()
+        self.model_optimizer.grad_scale = mdist.allreduce_gradients(self.model_optimizer.arena())
+        self.model_optimizer.step()
+        self.step += 1
+        return outputs, self.loss
+
+    def run_epoch(self):
+        for batch_indx, samples in enumerate(self.train_loader):
+            self.train_step(samples)
+            if self.verbose and self.rank == 0 and (batch_indx % max(1, self.log_freq) == 0):
+                print("epoch %d batch %d loss %.6f" % (self.epoch, batch_indx, float(sum(self.loss).detach())))
+        self.model_lr_scheduler.step()
+        if self.rank == 0 and self.save_checkpoints:
+            self.save_chkpnt()
+
+    def process_batch(self, samples, warp_test=False, semi_sup_pose=False):
+        dev = self.device
+        tgt = samples['tgt'].to(dev, non_blocking=True)
+        ref_imgs = [img.to(dev, non_blocking=True) for img in samples['ref_imgs']]
+        intrinsics = samples['intrinsics'].to(dev, non_blocking=True)
+        gt = samples['groundtruth']
+        disps = [self.depth_model(image_t) for image_t in (tgt, ref_imgs[0])]     # two separate passes, as the reference
+        if semi_sup_pose:
+            poses = torch.cat((samples["oxts"][0].unsqueeze(1), samples["oxts"][1].unsqueeze(1)), 1).to(dev)
+        else:
+            poses = self.pose_model(tgt, ref_imgs)
+        if warp_test:
+            return [disps, poses]
+        loss = self.criterion.forward(tgt, ref_imgs, disps, poses, intrinsics, gt)
+        return [disps, poses], loss
+
+    @torch.no_grad()
+    def validate(self):
+        from evaluate import compute_errors
+        self.set_eval()
+        acc = None
+        for samples in self.validation_loader:
+            outputs = self.process_batch(samples, warp_test=True)
+            acc = compute_errors(samples['groundtruth'].clamp_min(1e-3), outputs[0][0][0])
+        self.set_train()
+        return acc
