@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--layer-report", default=None, help="write a per-launch table of the instrumented step to this file")
     args = ap.parse_args()
 
     from mcav import dist as mdist
@@ -149,10 +150,18 @@ def main():
         # instrumented step(s): every conv launch bracketed by events on the launch stream
         N.PROFILE = []
         N.PROFILE_LOSS = []
+        N.PROFILE_TAGS = [] if args.layer_report else None
         for _ in range(3):
             step()
         torch.cuda.synchronize()
         recs, N.PROFILE = N.PROFILE, None
+        if args.layer_report:
+            tags, N.PROFILE_TAGS = N.PROFILE_TAGS, None
+            n1 = len(recs) // 3
+            with open(args.layer_report, "w") as f:
+                for (kind, fl, e0, e1), tag in zip(recs[2 * n1:], tags[2 * n1:]):
+                    ms1 = e0.elapsed_time(e1)
+                    f.write("%-6s %-58s %8.2f GF %8.3f ms %7.2f TF/s\n" % (kind, tag, fl / 1e9, ms1, fl / (ms1 * 1e-3) / 1e12))
         lrecs, N.PROFILE_LOSS = N.PROFILE_LOSS, None
         ms = sum(e0.elapsed_time(e1) for (_, _, e0, e1) in recs) / 3.0
         flops = sum(f for (_, f, _, _) in recs) / 3.0

@@ -1,0 +1,58 @@
+"""CPU, 2 gloo ranks: the data-parallel pieces (index sharding, one all-reduce on the flat gradient arena)."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG, REPO
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from mcav import dist as mdist
+    from mcav.arena import Arena
+    r, w = mdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)                       # different initial weights per rank on purpose
+    params = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    a = Arena(params)
+    mdist.broadcast_parameters(a, 0)
+    params[0].grad.fill_(float(rank + 1))
+    params[1].grad.fill_(10.0 * (rank + 1))
+    scale = mdist.allreduce_gradients(a)
+    idx = mdist.shard_indices(list(range(11)))
+    out.put((rank, a.flat.clone(), a.gflat.clone(), scale, idx))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allreduce_and_sharding():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, f0, g0, s0, i0), (_, f1, g1, s1, i1) = res
+    assert torch.equal(f0, f1)                              # parameters broadcast from rank 0
+    assert torch.equal(g0, g1) and s0 == s1 == 0.5          # summed gradients, 1/world for Adam
+    assert float(g0[0]) == 3.0 and float(g0[16]) == 30.0    # 1+2 and 10+20 (second tensor starts at the 16-float slot)
+    assert i0 == [0, 1, 2, 3, 4] and i1 == [5, 6, 7, 8, 9]  # disjoint equal slices, remainder dropped

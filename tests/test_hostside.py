@@ -1,0 +1,85 @@
+"""CPU: host-side logic of the product package that needs no GPU (module structure, arenas, config plumbing)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, PKG
+
+
+def test_state_dict_keys_equal_reference():
+    """Parameter / buffer names and shapes are the reference's (dumped from its classes by make_golden.py)."""
+    from models.depth.resnet_dispnet import DepthDecoder, DispResNet
+    from models.pose.pose_net import PoseNet
+    want = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    for name, m in (("DispResNet", DispResNet()), ("PoseNet", PoseNet()), ("DepthDecoder", DepthDecoder(np.array([64, 64, 128, 256, 512])))):
+        got = {k: list(v.shape) for k, v in m.state_dict().items()}
+        assert got == want[name], name
+
+
+def test_state_dict_interchangeable_with_oracle():
+    from models.depth.resnet_dispnet import DispResNet
+    from oracle import nets as on
+    a, b = DispResNet(), on.DispResNet()
+    b.load_state_dict(a.state_dict())
+    a.load_state_dict(b.state_dict())
+
+
+def test_arena_views_and_grads():
+    from mcav.arena import Arena, arena_of
+    from models.pose.pose_net import PoseNet
+    m = PoseNet()
+    m.init_weights()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    params = list(m.parameters())
+    a = Arena(params)
+    assert a.intact() and a.numel >= sum(p.numel() for p in params)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    # parameters and gradients are views of the flat buffers
+    a.flat.add_(1.0)
+    assert torch.equal(m.state_dict()["conv1.0.weight"], before["conv1.0.weight"] + 1.0)
+    params[0].grad.fill_(2.0)
+    assert float(a.gflat[:params[0].numel()].min()) == 2.0
+    a.zero_grad()
+    assert float(params[0].grad.abs().max()) == 0.0
+    assert arena_of(params) is a
+    # load_state_dict copies in place: views survive
+    m.load_state_dict(before)
+    assert a.intact()
+    # a re-allocation (e.g. module.to()) is detected
+    params[3].data = params[3].data.clone()
+    assert not a.intact()
+
+
+def test_config_schema_is_the_references():
+    import yaml
+    cfg = yaml.full_load(open(os.path.join(PKG, "configs", "basic_config.yaml")))
+    ref_keys = {"model": {"name", "depth", "pose"}, "datasets": {"path", "split", "augmentation", "sequence_length", "dataset"},
+                "action": {"mode", "MLOps", "log_freq", "from_scratch", "split", "random_seed", "batch_size", "num_epochs", "num_workers",
+                           "optimizer", "scheduler"}}
+    for sec, keys in ref_keys.items():
+        assert keys <= set(cfg[sec]), sec
+    assert {"name", "file"} <= set(cfg["model"]["depth"]) and {"name", "file"} <= set(cfg["model"]["pose"])
+
+
+def test_trainer_needs_gpu_and_fails_loudly():
+    import yaml
+    from trainer import Trainer
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cfg = yaml.full_load(open(os.path.join(PKG, "configs", "basic_config.yaml")))
+    with pytest.raises(RuntimeError):
+        Trainer(cfg)
+
+
+def test_synthetic_dataset_sample_contract():
+    import yaml
+    from dataloaders import UnSupKittiDataset
+    cfg = yaml.full_load(open(os.path.join(PKG, "configs", "basic_config.yaml")))
+    ds = UnSupKittiDataset(cfg)
+    s = ds[3]
+    assert s["tgt"].shape == (3, 192, 640) and len(s["ref_imgs"]) == 2 and s["intrinsics"].dtype == torch.float64
+    assert torch.equal(ds[3]["tgt"], s["tgt"])

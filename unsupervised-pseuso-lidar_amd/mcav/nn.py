@@ -61,11 +61,12 @@ L.register({
 # bench.py's instrumented step: when PROFILE is a list every conv launch is bracketed by events on the launch stream
 PROFILE = None
 PROFILE_LOSS = None
+PROFILE_TAGS = None
 
 
 class _Timed:
-    def __init__(self, kind, flops):
-        self.kind, self.flops = kind, flops
+    def __init__(self, kind, flops, tag=""):
+        self.kind, self.flops, self.tag = kind, flops, tag
 
     def __enter__(self):
         if PROFILE is not None:
@@ -78,6 +79,8 @@ class _Timed:
         if PROFILE is not None:
             self.e1.record()
             PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+            if PROFILE_TAGS is not None:
+                PROFILE_TAGS.append(self.tag)
         return False
 
 
@@ -167,7 +170,8 @@ def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0):
             raise L.MCAVError("mcav_igemm_mtiles: invalid descriptor (%d)" % mt)
         slab = empty((mt, 2, spec.cout), x1)
         d.stats = P(slab)
-    with _Timed("fwd", 2.0 * B * Hd * Wd * spec.cout * spec.cin * spec.kh * spec.kw):
+    with _Timed("fwd", 2.0 * B * Hd * Wd * spec.cout * spec.cin * spec.kh * spec.kw,
+                "M=%d N=%d K=%dx%d s%d %dx%d" % (B * Hd * Wd, spec.cout, spec.cin, spec.kh * spec.kw, spec.stride, Hd, Wd)):
         L.check(h.mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(fwd)")
     return (y, slab) if stats else y
 
@@ -202,7 +206,8 @@ def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=N
     d.bias, d.act = None, ACT_NONE
     d.dact_aux, d.dact, d.addend, d.pool = P(dact_aux), dact, P(addend), int(pool)
     d.tile = tile
-    with _Timed("dgrad", 2.0 * B * Hd * Wd * Cout * n_count * spec.kh * spec.kw):
+    with _Timed("dgrad", 2.0 * B * Hd * Wd * Cout * n_count * spec.kh * spec.kw,
+                "M=%d N=%d K=%dx%d s%d mode%d pool%d %dx%d" % (B * Hs * Ws, n_count, Cout, spec.kh * spec.kw, spec.stride, d.mode, int(pool), Hs, Ws)):
         L.check(L.lib().mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(dgrad)")
     return y
 
@@ -228,7 +233,8 @@ def conv_wgrad(spec, x1, dy, x2=None, up1=False, tile=0):
     if nbytes == 0:
         raise L.MCAVError("mcav_wgrad: invalid descriptor")
     ws = L.workspace(nbytes, x1.device, "wgrad")
-    with _Timed("wgrad", 2.0 * B * dy.shape[1] * dy.shape[2] * spec.cout * spec.cin * spec.kh * spec.kw):
+    with _Timed("wgrad", 2.0 * B * dy.shape[1] * dy.shape[2] * spec.cout * spec.cin * spec.kh * spec.kw,
+                "pix=%d Cout=%d Ktot=%dx%d s%d" % (B * dy.shape[1] * dy.shape[2], spec.cout, spec.cin, spec.kh * spec.kw, spec.stride)):
         L.check(h.mcav_wgrad(ctypes.byref(d), P(ws), ws.numel(), L.stream()), "mcav_wgrad")
 
 
