@@ -100,7 +100,29 @@ __device__ __forceinline__ float act_bwd(float y, int act) {
     return 1.f;
 }
 
-template <class T>
+// Kernel kinds (compile-time specialisations of the A-operand gather; the generic one handles everything):
+//   K_FAST    DIRECT gather, every source tensor has a multiple of 4 channels: one source pixel per (row, tap), offsets cached
+//             per tap, BRANCH-FREE 16-byte loads (invalid rows load from offset 0 and are zeroed by a select) so that the
+//             compiler keeps all loads of a tile in flight behind one counted s_waitcnt
+//   K_REFLADJ adjoint of the 3x3 reflection-padded conv: same as K_FAST away from the image border; wavefronts that touch the
+//             border (wave-uniform test) take 4 predicated loads per row instead of 1
+//   K_GENERIC any mode / any channel count (image stem, stride-2 adjoint, 1-channel disparity maps)
+enum { K_FAST = 0, K_REFLADJ = 1, K_GENERIC = 2 };
+
+// Raw buffer loads: an offset at or beyond num_records reads as zero in hardware, so padding / out-of-image rows need
+// neither a branch nor a select after the load (either would force an s_waitcnt right behind it).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;      // "reads as zero": every tensor here is < 2 GiB (checked on the host)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
+}
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
+template <class T, int KIND>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     constexpr int BM = T::BM, BN = T::BN;
     __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
@@ -135,14 +157,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     // ---- K-tile enumeration: (tap, chunk); ADJ_STRIDE2 tiles only visit the taps of their parity class
     const int nchunks = g.mode == MCAV_G_SMALLC ? 1 : p.Kp / CK;
     int cls_py = 0, cls_px = 0;
-    if (g.mode == MCAV_G_ADJ_STRIDE2) { const int cls = m0 / p.McP; cls_py = cls >> 1; cls_px = cls & 1; }
+    if (KIND == K_GENERIC && g.mode == MCAV_G_ADJ_STRIDE2) { const int cls = m0 / p.McP; cls_py = cls >> 1; cls_px = cls & 1; }
     auto tap_ok = [&](int tap) -> bool {
-        if (g.mode != MCAV_G_ADJ_STRIDE2) return true;
+        if (KIND != K_GENERIC || g.mode != MCAV_G_ADJ_STRIDE2) return true;
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
         return (((cls_py + g.offset - ky) | (cls_px + g.offset - kx)) & 1) == 0;
     };
     int T_total;
-    if (g.mode == MCAV_G_SMALLC) {
+    if (KIND == K_GENERIC && g.mode == MCAV_G_SMALLC) {
         T_total = (p.taps * 4 + CK - 1) / CK;
     } else {
         int nv = 0;
@@ -150,34 +172,106 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         T_total = nv * nchunks;
     }
     int tap = 0, chunk = 0;
-    if (g.mode != MCAV_G_SMALLC) while (tap < p.taps && !tap_ok(tap)) ++tap;
+    if (!(KIND == K_GENERIC && g.mode == MCAV_G_SMALLC)) while (tap < p.taps && !tap_ok(tap)) ++tap;
 
-    f32x4 ra[T::AROWS], rb[T::BVECS];
-    auto load_tile = [&]() {      // global -> registers for the tile at (tap, chunk)
+    // ---- cached per-row source BYTE offsets of the current tap (K_FAST / K_REFLADJ); OOB = reads as zero
+    unsigned o1[T::AROWS], o2[T::AROWS];
+    bool wave_border = false;          // K_REFLADJ: some row of this wavefront lies within 2 pixels of the image border
+    if (KIND == K_REFLADJ) {
+        bool b = false;
+#pragma unroll
+        for (int j = 0; j < T::AROWS; ++j) b = b || (rn[j] >= 0 && (ry[j] <= 1 || ry[j] >= g.Hs - 2 || rx[j] <= 1 || rx[j] >= g.Ws - 2));
+        wave_border = __any(b);
+    }
+    const unsigned bytes1 = (unsigned)((size_t)g.B * (g.up1 ? (g.Hs >> 1) * (g.Ws >> 1) : g.Hs * g.Ws) * g.C1 * 4);
+    const unsigned bytes2 = (unsigned)((size_t)g.B * g.Hs * g.Ws * g.C2 * 4);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1, bytes1);
+    const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(g.C2 > 0 ? g.x2 : g.x1, g.C2 > 0 ? bytes2 : 0u);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, (unsigned)((size_t)(p.n_begin + p.n_count) * p.Kstride * 4));
+    auto refresh_offsets = [&]() {
+        if (KIND == K_GENERIC) return;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+#pragma unroll
+        for (int j = 0; j < T::AROWS; ++j) {
+            int sy, sx;
+            bool ok = rn[j] >= 0;
+            if (KIND == K_FAST) {
+                sy = ry[j] * g.stride + g.sign * ky + g.offset;
+                sx = rx[j] * g.stride + g.sign * kx + g.offset;
+                if (g.pad_mode == MCAV_PAD_REFLECT) {
+                    sy = reflect_idx(sy, g.Hs);
+                    sx = reflect_idx(sx, g.Ws);
+                }
+            } else {
+                sy = ry[j] + 1 - ky;
+                sx = rx[j] + 1 - kx;
+            }
+            ok = ok && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
+            const int pix = (rn[j] * g.Hs + sy) * g.Ws + sx;
+            const int pix1 = g.up1 ? ((rn[j] * (g.Hs >> 1) + (sy >> 1)) * (g.Ws >> 1) + (sx >> 1)) : pix;
+            o1[j] = ok ? (unsigned)(pix1 * g.C1) * 4u : OOB;
+            o2[j] = ok ? (unsigned)(pix * g.C2) * 4u : OOB;
+        }
+    };
+    refresh_offsets();
+
+    auto load_tile = [&](f32x4 (&ra)[T::AROWS], f32x4 (&rb)[T::BVECS]) {      // global -> registers for the tile at (tap, chunk)
         int ky, kx, c, kflat;
-        if (g.mode == MCAV_G_SMALLC) {
+        if (KIND == K_GENERIC && g.mode == MCAV_G_SMALLC) {
             const int t4 = chunk * 4 + c4;             // every 16-byte column is its own tap
             ky = t4 / p.kw; kx = t4 - ky * p.kw; c = 0; kflat = chunk * CK;
             if (t4 >= p.taps) ky = -1;
         } else {
             ky = tap / p.kw; kx = tap - ky * p.kw; c = chunk * CK + c4 * 4; kflat = tap * p.Kp + chunk * CK;
         }
+        if constexpr (KIND == K_GENERIC) {
 #pragma unroll
-        for (int j = 0; j < T::AROWS; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (rn[j] >= 0 && ky >= 0) v = gather4(g, rn[j], ry[j], rx[j], ky, kx, c);
-            ra[j] = v;
+            for (int j = 0; j < T::AROWS; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (rn[j] >= 0 && ky >= 0) v = gather4(g, rn[j], ry[j], rx[j], ky, kx, c);
+                ra[j] = v;
+            }
+        } else {
+            // the whole 16-channel chunk lies in x1 or in x2 (C1 % 16 == 0 whenever there is an x2): wave-uniform choice
+            const bool use2 = chunk * CK >= g.C1;
+            const int cc = use2 ? c - g.C1 : c;
+            const bool cok = use2 ? cc < g.C2 : cc < g.C1;     // K padding beyond the real channels reads as zero
+            if (use2) {
+#pragma unroll
+                for (int j = 0; j < T::AROWS; ++j) ra[j] = buf_load4(rs2, cok ? o2[j] + (unsigned)cc * 4u : OOB);
+            } else {
+#pragma unroll
+                for (int j = 0; j < T::AROWS; ++j) ra[j] = buf_load4(rs1, cok ? o1[j] + (unsigned)cc * 4u : OOB);
+            }
+            if (KIND == K_REFLADJ && wave_border) {
+                // border rows: add the output(s) whose reflected tap landed on this pixel (at most one extra row, one extra column)
+#pragma unroll
+                for (int j = 0; j < T::AROWS; ++j) {
+                    const int dy = ry[j], dx = rx[j];
+                    const int sy = dy + 1 - ky, sx = dx + 1 - kx;
+                    const int ey = (dy == 1 && ky == 0) ? 0 : ((dy == g.Hs - 2 && ky == 2) ? g.Hs - 1 : -1);
+                    const int ex = (dx == 1 && kx == 0) ? 0 : ((dx == g.Ws - 2 && kx == 2) ? g.Ws - 1 : -1);
+                    const bool rok = rn[j] >= 0 && cok;
+                    const bool syok = (unsigned)sy < (unsigned)g.Hs, sxok = (unsigned)sx < (unsigned)g.Ws;
+                    const int rowb = rn[j] * g.Hs;
+                    const unsigned a0 = (unsigned)((((rowb + ey) * g.Ws + sx) * g.C1 + c) * 4);
+                    const unsigned a1 = (unsigned)((((rowb + sy) * g.Ws + ex) * g.C1 + c) * 4);
+                    const unsigned a2 = (unsigned)((((rowb + ey) * g.Ws + ex) * g.C1 + c) * 4);
+                    const f32x4 e0 = buf_load4(rs1, (rok && ey >= 0 && sxok) ? a0 : OOB);
+                    const f32x4 e1 = buf_load4(rs1, (rok && ex >= 0 && syok) ? a1 : OOB);
+                    const f32x4 e2 = buf_load4(rs1, (rok && ey >= 0 && ex >= 0) ? a2 : OOB);
+                    ra[j] += (e0 + e1) + e2;
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < T::BVECS; ++j) {
             const int e = tid + 256 * j, nn = e >> 2;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (nn < BN && n0 + nn < p.n_count)
-                v = *reinterpret_cast<const f32x4*>(p.w + (size_t)(p.n_begin + n0 + nn) * p.Kstride + kflat + (e & 3) * 4);
-            rb[j] = v;
+            const bool ok = nn < BN && n0 + nn < p.n_count;
+            rb[j] = buf_load4(rsw, ok ? (unsigned)(((p.n_begin + n0 + nn) * p.Kstride + kflat + (e & 3) * 4) * 4) : OOB);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](const f32x4 (&ra)[T::AROWS], const f32x4 (&rb)[T::BVECS], int buf) {
 #pragma unroll
         for (int j = 0; j < T::AROWS; ++j) *reinterpret_cast<f32x4*>(&As[buf][r0 + 64 * j][c4 * 4]) = ra[j];
 #pragma unroll
@@ -187,8 +281,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         }
     };
     auto advance = [&]() {
-        if (g.mode == MCAV_G_SMALLC) { ++chunk; return; }
-        if (++chunk == nchunks) { chunk = 0; do { ++tap; } while (tap < p.taps && !tap_ok(tap)); }
+        if (KIND == K_GENERIC && g.mode == MCAV_G_SMALLC) { ++chunk; return; }
+        if (++chunk == nchunks) {
+            chunk = 0;
+            do { ++tap; } while (tap < p.taps && !tap_ok(tap));
+            if (tap < p.taps) refresh_offsets();
+        }
     };
 
     // ---- accumulators
@@ -201,15 +299,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int r = 0; r < T::ACC; ++r) acc[i][j][r] = 0.f;
 
-    if (T_total > 0) {
-        load_tile();
-        store_tile(0);
-    }
-    __syncthreads();
-
-    for (int t = 0; t < T_total; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < T_total) { advance(); load_tile(); }
+    auto compute = [&](int buf) {
         if constexpr (T::MF == 32) {
             const int frow = lane & 31, fk = (lane >> 5) * 4;
 #pragma unroll
@@ -224,9 +314,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
                     for (int i = 0; i < T::TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < T::TN; ++j) {
+                        for (int j = 0; j < T::TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
-                        }
             }
         } else {
             const int frow = lane & 15, fk = (lane >> 4) * 4;
@@ -240,11 +329,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
                 for (int i = 0; i < T::TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < T::TN; ++j) {
+                    for (int j = 0; j < T::TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
-                    }
         }
-        if (t + 1 < T_total) store_tile(buf ^ 1);
+    };
+
+    // ---- main loop: tile t is computed from LDS buffer t & 1 while the loads of tiles t + 1 and t + 2 are in flight
+    // (two register stages), so a load has a full iteration plus an MFMA phase to land before it is written to LDS.
+    f32x4 ra0[T::AROWS], rb0[T::BVECS], ra1[T::AROWS], rb1[T::BVECS];
+    if (T_total > 0) load_tile(ra0, rb0);
+    if (T_total > 1) { advance(); load_tile(ra1, rb1); }
+    if (T_total > 0) store_tile(ra0, rb0, 0);
+    __syncthreads();
+    for (int t = 0; t < T_total; t += 2) {
+        if (t + 2 < T_total) { advance(); load_tile(ra0, rb0); }
+        compute(0);
+        if (t + 1 < T_total) store_tile(ra1, rb1, 1);
+        __syncthreads();
+        if (t + 1 >= T_total) break;
+        if (t + 3 < T_total) { advance(); load_tile(ra1, rb1); }
+        compute(1);
+        if (t + 2 < T_total) store_tile(ra0, rb0, 0);
         __syncthreads();
     }
 
@@ -334,13 +439,14 @@ struct WgradParams {
     int Mpix;                      // B * Hd * Wd
     int splits, pix_per_split;     // pixel ranges per workgroup (multiple of KP)
     int mtiles, ntiles;
-    float* slab;                   // [splits][Ktot][CoutP16]
+    float* slab;                   // [splits][Ktot + 1][slabN]; row Ktot holds the per-split column sums of dy (bias gradient)
     int slabN;                     // row stride of the slab (Cout rounded up to 16)
+    int want_bias;
 };
 
 constexpr int KP = 32;   // pixels per K-tile of the wgrad GEMM
 
-template <class T>
+template <class T, int KIND>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     constexpr int BM = T::BM, BN = T::BN;
     __shared__ __attribute__((aligned(16))) float Xs[2][KP][BM];   // [pixel][kflat]  (A operand, k-major)
@@ -356,7 +462,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     constexpr int ACOLS = BM / 4;                       // float4 columns
     constexpr int APIX = 256 / ACOLS;                   // pixels covered per pass (BM=128: 8, BM=64: 16, BM=256: 4)
     constexpr int APASS = KP / APIX;
-    const int acol = tid % ACOLS, apix = tid / ACOLS;
+    // a wavefront owns ACOLS/4 consecutive 16-byte columns (contiguous bytes per pixel: coalesced loads, conflict-free
+    // ds_write_b128) of 64/(ACOLS/4) pixels: its channel range is one 4*ACOLS/4-wide group, i.e. it lies in x1 or in x2
+    constexpr int CPW = ACOLS / 4;
+    const int acol = wave * CPW + lane % CPW, apix = lane / CPW;
     const int kflat = m0 + acol * 4;
     int aky = -1, akx = 0, ac = 0;
     if (kflat < p.Ktot) {
@@ -387,16 +496,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         x += by;
         while (x >= p.Wd) { x -= p.Wd; if (++y == p.Hd) { y = 0; ++n; } }
     };
-    f32x4 ra[APASS], rb[BPASS];
-    auto load_tile = [&](int t) {      // must be called with t = 0, 1, 2, ... in order
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.want_bias && mt == 0;
+    // K_FAST: branch-free raw buffer loads (out-of-range offset reads as zero), x1/x2 chosen per wavefront
+    const bool use2 = KIND == K_FAST && __builtin_amdgcn_readfirstlane((int)(g.C2 > 0 && ac >= g.C1)) != 0;
+    const unsigned bytes1 = (unsigned)((size_t)g.B * (g.up1 ? (g.Hs >> 1) * (g.Ws >> 1) : g.Hs * g.Ws) * g.C1 * 4);
+    const unsigned bytes2 = (unsigned)((size_t)g.B * g.Hs * g.Ws * g.C2 * 4);
+    const __amdgpu_buffer_rsrc_t rsx = use2 ? make_rsrc(g.x2, bytes2) : make_rsrc(g.x1, bytes1);
+    const __amdgpu_buffer_rsrc_t rsy = make_rsrc(p.dy, (unsigned)((size_t)p.Mpix * p.Cdy * 4));
+    const int acc_ = use2 ? ac - g.C1 : ac;                                    // channel inside the chosen source
+    const int Csrc = use2 ? g.C2 : g.C1;
+    const bool a_ok = aky >= 0 && acc_ < Csrc;
+    auto load_tile = [&](int t, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {      // must be called with t = 0, 1, 2, ... in order
         const int pb = pix_begin + t * KP;
         int n = pn, dy = py, dx = px;
 #pragma unroll
         for (int j = 0; j < APASS; ++j) {
             const int m = pb + apix + j * APIX;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < pix_end && aky >= 0) v = gather4(g, n, dy, dx, aky, akx, ac);
-            ra[j] = v;
+            if constexpr (KIND == K_FAST) {
+                int sy = dy * g.stride + aky + g.offset, sx = dx * g.stride + akx + g.offset;      // sign = +1 (forward gather)
+                if (g.pad_mode == MCAV_PAD_REFLECT) {
+                    sy = reflect_idx(sy, g.Hs);
+                    sx = reflect_idx(sx, g.Ws);
+                }
+                const bool ok = a_ok && m < pix_end && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
+                const int pix = (!use2 && g.up1) ? ((n * (g.Hs >> 1) + (sy >> 1)) * (g.Ws >> 1) + (sx >> 1)) : ((n * g.Hs + sy) * g.Ws + sx);
+                ra[j] = buf_load4(rsx, ok ? (unsigned)(pix * Csrc + acc_) * 4u : OOB);
+            } else {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m < pix_end && aky >= 0) v = gather4(g, n, dy, dx, aky, akx, ac);
+                ra[j] = v;
+            }
             step_pix(n, dy, dx, APIX);
         }
         pn = n; py = dy; px = dx;       // APASS * APIX == KP: now at this thread's first row of tile t + 1
@@ -404,6 +534,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         for (int j = 0; j < BPASS; ++j) {
             const int pl = bpix + j * BPIX;
             const int m = pb + pl;
+            if constexpr (KIND == K_FAST) {
+                const int c = n0 + bcol * 4;
+                const bool ok = pl < KP && m < pix_end && c + 4 <= p.Cout;
+                rb[j] = buf_load4(rsy, ok ? (unsigned)(m * p.Cdy + p.dy_choff + c) * 4u : OOB);
+                if (do_bias) bsum += rb[j];
+                continue;
+            }
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (pl < KP && m < pix_end) {
                 const int c = n0 + bcol * 4;
@@ -418,9 +555,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                 }
             }
             rb[j] = v;
+            if (do_bias) bsum += v;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const f32x4 (&ra)[APASS], const f32x4 (&rb)[BPASS]) {
 #pragma unroll
         for (int j = 0; j < APASS; ++j) *reinterpret_cast<f32x4*>(&Xs[buf][apix + j * APIX][acol * 4]) = ra[j];
 #pragma unroll
@@ -439,11 +577,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int r = 0; r < T::ACC; ++r) acc[i][j][r] = 0.f;
 
-    if (T_total > 0) { load_tile(0); store_tile(0); }
-    __syncthreads();
-    for (int t = 0; t < T_total; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < T_total) load_tile(t + 1);
+    auto compute = [&](int buf) {
         if constexpr (T::MF == 32) {
             const int fr = lane & 31, fk = lane >> 5;
 #pragma unroll
@@ -477,13 +611,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                     }
             }
         }
-        if (t + 1 < T_total) store_tile(buf ^ 1);
+    };
+    f32x4 ra0[APASS], rb0[BPASS], ra1[APASS], rb1[BPASS];
+    if (T_total > 0) load_tile(0, ra0, rb0);
+    if (T_total > 1) load_tile(1, ra1, rb1);
+    if (T_total > 0) store_tile(0, ra0, rb0);
+    __syncthreads();
+    for (int t = 0; t < T_total; t += 2) {
+        if (t + 2 < T_total) load_tile(t + 2, ra0, rb0);
+        compute(0);
+        if (t + 1 < T_total) store_tile(1, ra1, rb1);
+        __syncthreads();
+        if (t + 1 >= T_total) break;
+        if (t + 3 < T_total) load_tile(t + 3, ra1, rb1);
+        compute(1);
+        if (t + 2 < T_total) store_tile(0, ra0, rb0);
         __syncthreads();
     }
 
     constexpr int MF = T::MF;
     const int ccol = lane & (MF - 1);
-    float* slab = p.slab + (size_t)split * p.Ktot * p.slabN;
+    float* slab = p.slab + (size_t)split * (p.Ktot + 1) * p.slabN;
+    if (do_bias) {      // column sums of dy over this split's pixels: lanes with the same column group, then the pixel lanes
+        if (bpix < BPIX) *reinterpret_cast<f32x4*>(&Ys[0][bpix][bcol * 4]) = bsum;
+        __syncthreads();
+        if (tid < BN) {
+            float t = 0.f;
+            for (int k = 0; k < BPIX; ++k) t += Ys[0][k][tid];
+            if (n0 + tid < p.slabN) slab[(size_t)p.Ktot * p.slabN + n0 + tid] = t;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < T::TM; ++i)
 #pragma unroll
@@ -497,37 +654,52 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         }
 }
 
-// slab [splits][Ktot][slabN] -> OIHW gradient (fixed summation order; optional accumulate)
-__global__ void wgrad_reduce_kernel(const float* slab, int splits, int Ktot, int slabN, int Kp, int taps, int Cout, int Cin, float* dw, int accumulate) {
-    const int total = Cout * Cin * taps;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int co = e / (Cin * taps), r = e - co * (Cin * taps);
-        const int ci = r / taps, tap = r - ci * taps;
-        const size_t src = (size_t)(tap * Kp + ci) * slabN + co;
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += slab[(size_t)k * Ktot * slabN + src];
-        dw[e] = accumulate ? dw[e] + s : s;
-    }
+// First reduction level when there are many pixel splits: dst[g][e] = sum of the splits of group g (fixed order).
+__global__ __launch_bounds__(256) void wgrad_presum_kernel(const float* slab, int splits, size_t elems, int per_group, float* dst) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= elems) return;
+    const int k0 = blockIdx.y * per_group, k1 = min(splits, k0 + per_group);
+    float s = 0.f;
+    for (int k = k0; k < k1; ++k) s += slab[(size_t)k * elems + e];
+    dst[(size_t)blockIdx.y * elems + e] = s;
 }
 
-// column sums of dy over pixels -> dbias (two-stage, fixed order)
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* dy, int Mpix, int Cdy, int choff, int Cout, float* part, int nblk) {
-    // block handles pixel range; thread t handles channel t % Cq ... generic strided accumulation
-    const int per = (Mpix + nblk - 1) / nblk;
-    const int pb = blockIdx.x * per, pe = min(Mpix, pb + per);
-    for (int c = threadIdx.x; c < Cout; c += 256) {
-        float s = 0.f;
-        for (int m = pb; m < pe; ++m) s += dy[(size_t)m * Cdy + choff + c];
-        part[(size_t)blockIdx.x * Cout + c] = s;
+// slab [splits][Ktot + 1][slabN] -> OIHW gradient (+ bias gradient), fixed summation order, optional accumulate.
+// One block owns 32 output channels x CI_T input channels x all taps: slab reads are coalesced along the output channel,
+// the tile is transposed through LDS, and each output channel's run of CI_T * taps floats is written contiguously.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, int splits, int Ktot, int slabN, int Kp, int taps, int Cout, int Cin,
+                                                           int CI_T, float* dw, float* dbias, int accumulate) {
+    extern __shared__ float lds[];
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * CI_T;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int run = CI_T * taps, stride = run + 1;
+    const size_t split_stride = (size_t)(Ktot + 1) * slabN;
+    const bool col_ok = co0 + tx < slabN;
+    for (int idx = ty; idx < run; idx += 8) {
+        const int tap = idx / CI_T, r = idx - tap * CI_T, ci = ci0 + r;
+        float sum = 0.f;
+        if (ci < Cin && col_ok) {
+            const float* src = slab + (size_t)(tap * Kp + ci) * slabN + co0 + tx;
+            for (int k = 0; k < splits; ++k) sum += src[(size_t)k * split_stride];
+        }
+        lds[tx * stride + r * taps + tap] = sum;
     }
-}
-
-__global__ void colsum_final_kernel(const float* part, int nblk, int Cout, float* out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cout) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * Cout + c];
-    out[c] = accumulate ? out[c] + (float)s : (float)s;
+    if (dbias && blockIdx.y == 0 && ty == 0 && co0 + tx < Cout) {
+        const float* src = slab + (size_t)Ktot * slabN + co0 + tx;
+        float sum = 0.f;
+        for (int k = 0; k < splits; ++k) sum += src[(size_t)k * split_stride];
+        dbias[co0 + tx] = accumulate ? dbias[co0 + tx] + sum : sum;
+    }
+    __syncthreads();
+    const int valid_run = (Cin - ci0 < CI_T ? Cin - ci0 : CI_T) * taps;
+    for (int e = threadIdx.x; e < 32 * run; e += 256) {
+        const int col = e / run, q = e - col * run;
+        if (co0 + col < Cout && q < valid_run) {
+            const size_t o = ((size_t)(co0 + col) * Cin + ci0) * taps + q;
+            const float v = lds[col * stride + q];
+            dw[o] = accumulate ? dw[o] + v : v;
+        }
+    }
 }
 
 // OIHW -> packed.  transposed = 0: packed[n = co][tap][k = ci];  transposed = 1: packed[n = ci][tap][k = co].
@@ -590,6 +762,8 @@ inline bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
     p.y = d->y; p.Hd = d->Hd; p.Wd = d->Wd; p.Cd = d->Cd; p.n_begin = d->n_begin; p.n_count = d->n_count; p.y_choff = d->y_choff;
     p.bias = d->bias; p.act = d->act; p.dact_aux = d->dact_aux; p.dact = d->dact; p.addend = d->addend; p.pool = d->pool; p.stats = d->stats;
     const long Mlin = (long)d->B * d->Hd * d->Wd;
+    if ((long)d->B * d->Hs * d->Ws * (d->C1 > d->C2 ? d->C1 : d->C2) * 4 >= 0x7fffffffL) return false;   // 32-bit byte offsets
+    if ((long)d->Np * kstride_of(d->kh * d->kw, d->Kp) * 4 >= 0x7fffffffL) return false;
     tile = pick_tile(d, Mlin);
     int BM, BN;
     tile_dims(tile, BM, BN);
@@ -609,7 +783,11 @@ inline bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
 
 template <class T>
 inline void launch_igemm(const IgemmParams& p, hipStream_t s) {
-    igemm_kernel<T><<<p.mtiles * p.ntiles, 256, 0, s>>>(p);
+    const bool c4ok = (p.g.C1 & 3) == 0 && (p.g.C2 & 3) == 0 && (p.g.C2 == 0 || (p.g.C1 & 15) == 0);
+    const int grid = p.mtiles * p.ntiles;
+    if (p.g.mode == MCAV_G_DIRECT && c4ok) igemm_kernel<T, K_FAST><<<grid, 256, 0, s>>>(p);
+    else if (p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0) igemm_kernel<T, K_REFLADJ><<<grid, 256, 0, s>>>(p);
+    else igemm_kernel<T, K_GENERIC><<<grid, 256, 0, s>>>(p);
 }
 
 }  // namespace mcav
@@ -645,8 +823,8 @@ namespace mcav {
 struct WgradPlan {
     WgradParams p;
     int tile;
-    size_t slab_bytes, part_bytes;
-    int colsum_blocks;
+    size_t slab_bytes, pre_bytes;
+    int ci_t, groups, per_group;
 };
 
 inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
@@ -664,6 +842,7 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     p.dy = d->dy; p.Hd = d->Hd; p.Wd = d->Wd; p.Cdy = d->Cdy; p.dy_choff = d->dy_choff; p.Cout = d->Cout;
     const long M = (long)d->B * d->Hd * d->Wd;
     if (M > 0x7fffffffL) return false;
+    if ((long)d->B * d->Hs * d->Ws * (d->C1 > d->C2 ? d->C1 : d->C2) * 4 >= 0x7fffffffL || M * d->Cdy * 4 >= 0x7fffffffL) return false;
     p.Mpix = (int)M;
     p.slabN = round_up(d->Cout, 16);
     int tile = d->tile;
@@ -682,18 +861,31 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     int splits = (1024 + out_tiles - 1) / out_tiles;             // aim at ~1024 workgroups
     const int max_splits = (p.Mpix + 8 * KP - 1) / (8 * KP);     // but at least 8 K-tiles each
     if (splits > max_splits) splits = max_splits;
+    if (splits > 512) splits = 512;
     if (splits < 1) splits = 1;
     p.pix_per_split = round_up((p.Mpix + splits - 1) / splits, KP);
     p.splits = (p.Mpix + p.pix_per_split - 1) / p.pix_per_split;
-    pl.slab_bytes = align_up(sizeof(float) * (size_t)p.splits * p.Ktot * p.slabN, 256);
-    pl.colsum_blocks = 256;
-    pl.part_bytes = align_up(sizeof(float) * (size_t)pl.colsum_blocks * d->Cout, 256);
+    p.want_bias = d->dbias != nullptr;
+    pl.slab_bytes = align_up(sizeof(float) * (size_t)p.splits * (p.Ktot + 1) * p.slabN, 256);
+    pl.groups = p.splits > 16 ? 16 : 0;                          // two-level reduction above 16 splits
+    pl.per_group = pl.groups ? (p.splits + pl.groups - 1) / pl.groups : 0;
+    if (pl.groups) pl.groups = (p.splits + pl.per_group - 1) / pl.per_group;
+    pl.pre_bytes = align_up(sizeof(float) * (size_t)pl.groups * (p.Ktot + 1) * p.slabN, 256);
+    int ci_t = 480 / p.taps;                                     // 32 x (CI_T * taps + 1) floats of LDS <= 64 KB
+    if (ci_t > 32) ci_t = 32;
+    if (ci_t >= 16) ci_t = ci_t / 16 * 16; else if (ci_t >= 8) ci_t = 8; else if (ci_t < 1) return false;
+    pl.ci_t = ci_t;
     return true;
 }
 
 template <class T>
 inline void launch_wgrad(const WgradParams& p, hipStream_t s) {
-    wgrad_kernel<T><<<p.splits * p.mtiles * p.ntiles, 256, 0, s>>>(p);
+    const int grid = p.splits * p.mtiles * p.ntiles;
+    const int wave_ch = T::BM / 4;          // channels one wavefront's A columns span
+    const bool fast = p.g.mode == MCAV_G_DIRECT && (p.g.C1 & 3) == 0 && (p.g.C2 & 3) == 0 && (p.g.C2 == 0 || p.g.C1 % wave_ch == 0) &&
+                      (p.Cout & 3) == 0 && (p.Cdy & 3) == 0 && (p.dy_choff & 3) == 0;
+    if (fast) wgrad_kernel<T, K_FAST><<<grid, 256, 0, s>>>(p);
+    else wgrad_kernel<T, K_GENERIC><<<grid, 256, 0, s>>>(p);
 }
 
 }  // namespace mcav
@@ -701,16 +893,15 @@ inline void launch_wgrad(const WgradParams& p, hipStream_t s) {
 MCAV_EXPORT size_t mcav_wgrad_workspace_bytes(const mcav_wgrad_desc* d) {
     WgradPlan pl;
     if (!plan_wgrad(d, pl)) return 0;
-    return pl.slab_bytes + pl.part_bytes;
+    return pl.slab_bytes + pl.pre_bytes;
 }
 
 MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
     WgradPlan pl;
     if (!plan_wgrad(d, pl) || !workspace) return MCAV_E_INVALID;
-    if (workspace_bytes < pl.slab_bytes + pl.part_bytes) return MCAV_E_WORKSPACE;
+    if (workspace_bytes < pl.slab_bytes + pl.pre_bytes) return MCAV_E_WORKSPACE;
     hipStream_t s = as_stream(stream);
     pl.p.slab = reinterpret_cast<float*>(workspace);
-    float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pl.slab_bytes);
     switch (pl.tile) {
         case 1: launch_wgrad<Tile128x64>(pl.p, s); break;
         case 2: launch_wgrad<Tile64x64>(pl.p, s); break;
@@ -719,13 +910,19 @@ MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t wor
         case 6: launch_wgrad<Tile64x16>(pl.p, s); break;
         default: return MCAV_E_INVALID;
     }
-    const int total = d->Cout * d->Cin * pl.p.taps;
-    wgrad_reduce_kernel<<<min((total + 255) / 256, 2048), 256, 0, s>>>(pl.p.slab, pl.p.splits, pl.p.Ktot, pl.p.slabN, pl.p.Kp, pl.p.taps, d->Cout,
-                                                                       d->Cin, d->dw_oihw, d->accumulate);
-    if (d->dbias) {
-        colsum_partial_kernel<<<pl.colsum_blocks, 256, 0, s>>>(d->dy, pl.p.Mpix, d->Cdy, d->dy_choff, d->Cout, part, pl.colsum_blocks);
-        colsum_final_kernel<<<(d->Cout + 63) / 64, 64, 0, s>>>(part, pl.colsum_blocks, d->Cout, d->dbias, d->accumulate);
+    const dim3 rgrid((d->Cout + 31) / 32, (d->Cin + pl.ci_t - 1) / pl.ci_t);
+    const size_t lds_bytes = sizeof(float) * 32 * (size_t)(pl.ci_t * pl.p.taps + 1);
+    const float* rsrc = pl.p.slab;
+    int rsplits = pl.p.splits;
+    if (pl.groups) {
+        float* pre = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pl.slab_bytes);
+        const size_t elems = (size_t)(pl.p.Ktot + 1) * pl.p.slabN;
+        wgrad_presum_kernel<<<dim3((unsigned)((elems + 255) / 256), pl.groups), 256, 0, s>>>(pl.p.slab, pl.p.splits, elems, pl.per_group, pre);
+        rsrc = pre;
+        rsplits = pl.groups;
     }
+    wgrad_reduce_kernel<<<rgrid, 256, lds_bytes, s>>>(rsrc, rsplits, pl.p.Ktot, pl.p.slabN, pl.p.Kp, pl.p.taps, d->Cout, d->Cin, pl.ci_t,
+                                                     d->dw_oihw, d->dbias, d->accumulate);
     return launch_status();
 }
 

@@ -86,7 +86,7 @@ __device__ __forceinline__ f32x4 relu_mask(f32x4 g, f32x4 y) {
 }
 
 // Per-block partial sums of dz and dz * xhat.  G = C/4 channel groups; a block covers PL = 256 / min(G,256) pixel lanes.
-constexpr int BNR_BLOCKS = 512;
+constexpr int BNR_BLOCKS = 256;
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* dy, const f32x4* yact, const f32x4* x, const f32x4* mean, const f32x4* invstd,
                                                             int relu, size_t n_pix, int C4, float* part /* [blocks][2][C] */) {
     __shared__ f32x4 sh[2][256];
@@ -120,18 +120,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* dy, con
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* part, int nblk, int C, float* dgamma, float* dbeta, int accumulate, float* sums) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, float* dgamma, float* dbeta, int accumulate, float* sums) {
+    __shared__ double s1[8][32], s2[8][32];
+    const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < nblk; ++k) {
-        a += (double)part[(size_t)k * 2 * C + c];
-        b += (double)part[(size_t)k * 2 * C + C + c];
+    if (c < C)
+        for (int k = slice; k < nblk; k += 8) {
+            a += (double)part[(size_t)k * 2 * C + c];
+            b += (double)part[(size_t)k * 2 * C + C + c];
+        }
+    s1[slice][cl] = a; s2[slice][cl] = b;
+    __syncthreads();
+    if (slice == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        sums[c] = (float)a;
+        sums[C + c] = (float)b;
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
     }
-    sums[c] = (float)a;
-    sums[C + c] = (float)b;
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* dy, const f32x4* yact, const f32x4* x, const f32x4* gamma, const f32x4* mean,
@@ -328,12 +334,12 @@ MCAV_EXPORT int mcav_bn_bwd_reduce(const float* dy, const float* y_act, const fl
     if (C4 < 256 && (256 % C4) != 0) return MCAV_E_INVALID;
     if (C4 > 256 && (C4 % 256) != 0) return MCAV_E_INVALID;
     if (workspace_bytes < mcav_bn_bwd_workspace_bytes(n_pix, C)) return MCAV_E_WORKSPACE;
-    int blocks = (int)(n_pix < (size_t)BNR_BLOCKS ? n_pix : (size_t)BNR_BLOCKS);
+    int blocks = (int)((n_pix + 31) / 32 < (size_t)BNR_BLOCKS ? (n_pix + 31) / 32 : (size_t)BNR_BLOCKS);
     float* part = reinterpret_cast<float*>(workspace);
     hipStream_t s = as_stream(stream);
     bn_bwd_reduce_kernel<<<blocks, 256, 0, s>>>((const f32x4*)dy, (const f32x4*)y_act, (const f32x4*)x, (const f32x4*)save_mean, (const f32x4*)save_invstd,
                                                 relu, n_pix, C4, part);
-    bn_bwd_finalize_kernel<<<(C + 63) / 64, 64, 0, s>>>(part, blocks, C, dgamma, dbeta, accumulate, sums);
+    bn_bwd_finalize_kernel<<<(C + 31) / 32, 256, 0, s>>>(part, blocks, C, dgamma, dbeta, accumulate, sums);
     return launch_status();
 }
 
