@@ -52,13 +52,13 @@ def build(device, lr=1e-4, seed=0):
     return depth, pose, opt, Losses()
 
 
-def make_step(depth, pose, opt, crit, samples):
+def make_step(depth, pose, opt, crit, samples, pair=True):
     from mcav import dist as mdist
     tgt, refs, K = samples["tgt"], samples["ref_imgs"], samples["intrinsics"]
 
     def step():
         opt.zero_grad()
-        disps = [depth(tgt), depth(refs[0])]
+        disps = list(depth.forward_pair(tgt, refs[0])) if pair else [depth(tgt), depth(refs[0])]
         poses = pose(tgt, refs)
         loss = crit.forward(tgt, refs, disps, poses, K, None)
         sum(loss).backward()
@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--separate-passes", action="store_true", help="run the two depth passes as separate launch sets (default: stacked)")
     ap.add_argument("--layer-report", default=None, help="write a per-launch table of the instrumented step to this file")
     args = ap.parse_args()
 
@@ -115,7 +116,7 @@ def main():
     mdist.broadcast_parameters(opt.arena())
     s = synthetic_samples(B, H, W, rank)
     samples = {"tgt": s["tgt"].to(device), "ref_imgs": [r.to(device) for r in s["ref_imgs"]], "intrinsics": s["intrinsics"].to(device)}
-    step = make_step(depth, pose, opt, crit, samples)
+    step = make_step(depth, pose, opt, crit, samples, pair=not args.separate_passes)
 
     def fence():
         if world > 1:

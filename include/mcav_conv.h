@@ -60,7 +60,10 @@ typedef struct mcav_igemm_desc {
     const float* addend;    /* same layout as y */
     int pool;               /* 1: destination pixels are visited in 2x2 blocks and summed: y is [B, Hd/2, Wd/2, Cd] */
     float* stats;           /* NULL or [mtiles][2][n_count]: per-tile column sums of y and y^2 (BatchNorm batch statistics) */
-    int tile;               /* 0 = choose automatically; else a tile-config id (see mcav_igemm_tile_info) */
+    int tile;               /* 0 = choose automatically; else a tile-config id */
+    int groups;             /* 0/1 = one group.  G > 1: the batch is G equal groups (e.g. the tgt and ref0 passes of the depth net run as
+                             * one launch); output tiles never straddle a group, so `stats` rows [g * mtiles/G, (g+1) * mtiles/G) belong to
+                             * group g (per-pass BatchNorm statistics).  Only with the DIRECT / SMALLC gathers and pool == 0. */
 } mcav_igemm_desc;
 
 /* number of M-tiles (rows of `stats`) the launch will use with its chosen tile config */
@@ -103,23 +106,26 @@ int mcav_nhwc_to_nchw(const float* src, int B, int C, int H, int W, int Cp, int 
  *   running_mean / running_var (unbiased) with `momentum`.  count = pixels per channel. */
 int mcav_bn_finalize(const float* stats, int mtiles, int C, double count, const float* gamma, const float* beta, float eps,
                      float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* save_mean,
-                     float* save_invstd, void* stream);
+                     float* save_invstd, int groups, void* stream);
+/* groups > 1: `stats` holds groups * mtiles rows, `count` is per group, scale/shift/save_* are [groups][C], and the running
+ * statistics are updated once per group, in group order (exactly as `groups` consecutive forward passes would). */
 /* eval mode: scale/shift from the running statistics */
 int mcav_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C,
                         float* scale, float* shift, void* stream);
-/* y = act(x * scale[c] + shift[c] (+ residual)); n_pix pixels of C channels; act = NONE or RELU */
+/* y = act(x * scale[g][c] + shift[g][c] (+ residual)); n_pix pixels of C channels; act = NONE or RELU;
+ * pix_per_group = pixels per group (0 = one group) */
 int mcav_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, int act, size_t n_pix, int C, float* y,
-                  void* stream);
+                  size_t pix_per_group, void* stream);
 /* backward, pass 1: dz = dy * (y > 0 if relu); per-channel sums of dz and dz * xhat -> dgamma, dbeta (accumulated if accumulate) */
-size_t mcav_bn_bwd_workspace_bytes(size_t n_pix, int C);
+size_t mcav_bn_bwd_workspace_bytes(size_t n_pix, int C, int groups);
 int mcav_bn_bwd_reduce(const float* dy, const float* y_act, const float* x, const float* save_mean, const float* save_invstd, int relu,
-                       size_t n_pix, int C, float* dgamma, float* dbeta, int accumulate, float* sums /* [2][C] out */,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       size_t n_pix, int C, float* dgamma, float* dbeta, int accumulate, float* sums /* [groups][2][C] out */,
+                       int groups, void* workspace, size_t workspace_bytes, void* stream);
 /* backward, pass 2: dx = gamma * invstd * (dz - sum_dz / N - xhat * sum_dz_xhat / N); optionally also stores dz (the
  * gradient flowing to the residual branch) to dres (added into it if dres_accumulate) */
 int mcav_bn_bwd_apply(const float* dy, const float* y_act, const float* x, const float* gamma, const float* save_mean,
                       const float* save_invstd, const float* sums, int relu, size_t n_pix, int C, float* dx, float* dres,
-                      int dres_accumulate, void* stream);
+                      int dres_accumulate, int groups, void* stream);
 
 /* MaxPool2d(3, stride 2, pad 1) on NHWC; idx stores the winning tap (0..8, first maximum in row-major window order). */
 int mcav_maxpool3s2_fwd(const float* x, int B, int H, int W, int C, float* y, uint8_t* idx, void* stream);

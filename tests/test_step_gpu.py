@@ -27,8 +27,8 @@ def build_pair(seed_d=141, seed_p=121):
     return hip_d.to(DEV).train(), hip_p.to(DEV).train(), ref_d.train(), ref_p.train()
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 64, 128), (3, 96, 160)])
-def test_train_step_vs_oracle(B, H, W):
+@pytest.mark.parametrize("B,H,W,pair", [(2, 64, 128, False), (3, 96, 160, False), (2, 64, 128, True), (3, 96, 160, True)])
+def test_train_step_vs_oracle(B, H, W, pair):
     from losses import Losses
     from mcav.optim import FusedAdam
     from oracle.step import make_optimizer, synthetic_batch, train_step
@@ -40,7 +40,7 @@ def test_train_step_vs_oracle(B, H, W):
     opt = FusedAdam(list(hip_d.parameters()) + list(hip_p.parameters()), 1e-4)
     tgt, refs, K = s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], s["intrinsics"].to(DEV)
     opt.zero_grad()
-    disps = [hip_d(tgt), hip_d(refs[0])]
+    disps = list(hip_d.forward_pair(tgt, refs[0])) if pair else [hip_d(tgt), hip_d(refs[0])]
     poses = hip_p(tgt, refs)
     loss = Losses().forward(tgt, refs, disps, poses, K, None)
     sum(loss).backward()

@@ -49,8 +49,9 @@ struct IgemmParams {
     const float* addend;
     int pool;
     float* stats;
-    int M;           // rows of the GEMM (incl. class padding for ADJ_STRIDE2)
-    int Mc, McP;     // ADJ_STRIDE2: pixels per parity class and its BM-padded size
+    int M;           // rows of the GEMM (incl. class / group padding)
+    int Mc, McP;     // ADJ_STRIDE2: pixels per parity class and its BM-padded size; groups > 1: rows per group and padded size
+    int groups;
     int mtiles, ntiles;
 };
 
@@ -68,6 +69,15 @@ __device__ __forceinline__ bool decode_row(const IgemmParams& p, int m, int& n, 
         return dy < p.Hd && dx < p.Wd;
     }
     if (m >= p.M) return false;
+    if (p.groups > 1) {      // group-major rows, each group padded to whole tiles
+        const int grp = m / p.McP, r = m - grp * p.McP;
+        if (r >= p.Mc) return false;
+        const int hw = p.Hd * p.Wd, ng = r / hw, q = r - ng * hw;
+        n = grp * (p.g.B / p.groups) + ng;
+        dy = q / p.Wd;
+        dx = q - dy * p.Wd;
+        return true;
+    }
     if (p.pool) {
         const int blk = m >> 2, q = m & 3;
         const int Hh = p.Hd >> 1, Wh = p.Wd >> 1;
@@ -494,7 +504,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
     auto step_pix = [&](int& n, int& y, int& x, int by) {
         x += by;
-        while (x >= p.Wd) { x -= p.Wd; if (++y == p.Hd) { y = 0; ++n; } }
+        if constexpr (KIND == K_FAST) {       // Wd >= APIX is a dispatch condition of the fast kind: at most one wrap
+            const bool wx = x >= p.Wd;
+            x = wx ? x - p.Wd : x;
+            y += wx ? 1 : 0;
+            const bool wy = y >= p.Hd;
+            y = wy ? 0 : y;
+            n += wy ? 1 : 0;
+        } else {
+            while (x >= p.Wd) { x -= p.Wd; if (++y == p.Hd) { y = 0; ++n; } }
+        }
     };
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const bool do_bias = p.want_bias && mt == 0;
@@ -538,7 +557,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                 const int c = n0 + bcol * 4;
                 const bool ok = pl < KP && m < pix_end && c + 4 <= p.Cout;
                 rb[j] = buf_load4(rsy, ok ? (unsigned)(m * p.Cdy + p.dy_choff + c) * 4u : OOB);
-                if (do_bias) bsum += rb[j];
                 continue;
             }
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -555,10 +573,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                 }
             }
             rb[j] = v;
-            if (do_bias) bsum += v;
         }
     };
     auto store_tile = [&](int buf, const f32x4 (&ra)[APASS], const f32x4 (&rb)[BPASS]) {
+        if (do_bias) {      // column sums of dy for the bias gradient, taken when the data has landed anyway
+#pragma unroll
+            for (int j = 0; j < BPASS; ++j) bsum += rb[j];
+        }
 #pragma unroll
         for (int j = 0; j < APASS; ++j) *reinterpret_cast<f32x4*>(&Xs[buf][apix + j * APIX][acol * 4]) = ra[j];
 #pragma unroll
@@ -580,35 +601,59 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     auto compute = [&](int buf) {
         if constexpr (T::MF == 32) {
             const int fr = lane & 31, fk = lane >> 5;
+            // operands of 4 k-steps form a batch; batch u+1 is read from LDS before the MFMAs of batch u are issued and the
+            // scheduler is fenced so that it cannot fold the reads back behind the MFMAs (one exposed LDS latency per tile)
+            constexpr int NB = KP / 2 / 4;
+            float a[2][4][T::TM], b[2][4][T::TN];
+            auto rd = [&](int s, int k0) {
 #pragma unroll
-            for (int kk = 0; kk < KP / 2; ++kk) {
-                float a[T::TM], b[T::TN];
+                for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                for (int i = 0; i < T::TM; ++i) a[i] = Xs[buf][kk * 2 + fk][wm0 + i * 32 + fr];
+                    for (int i = 0; i < T::TM; ++i) a[s][u][i] = Xs[buf][(k0 + u) * 2 + fk][wm0 + i * 32 + fr];
 #pragma unroll
-                for (int j = 0; j < T::TN; ++j) b[j] = Ys[buf][kk * 2 + fk][wn0 + j * 32 + fr];
+                    for (int j = 0; j < T::TN; ++j) b[s][u][j] = Ys[buf][(k0 + u) * 2 + fk][wn0 + j * 32 + fr];
+                }
+            };
+            rd(0, 0);
 #pragma unroll
-                for (int i = 0; i < T::TM; ++i)
+            for (int bt = 0; bt < NB; ++bt) {
+                if (bt + 1 < NB) rd((bt + 1) & 1, (bt + 1) * 4);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < T::TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-                    }
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < T::TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[bt & 1][u][i], b[bt & 1][u][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             const int fr = lane & 15, fk = lane >> 4;
+            constexpr int NB = KP / 4 / 4;
+            float a[2][4][T::TM], b[2][4][T::TN];
+            auto rd = [&](int s, int k0) {
 #pragma unroll
-            for (int kk = 0; kk < KP / 4; ++kk) {
-                float a[T::TM], b[T::TN];
+                for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                for (int i = 0; i < T::TM; ++i) a[i] = Xs[buf][kk * 4 + fk][wm0 + i * 16 + fr];
+                    for (int i = 0; i < T::TM; ++i) a[s][u][i] = Xs[buf][(k0 + u) * 4 + fk][wm0 + i * 16 + fr];
 #pragma unroll
-                for (int j = 0; j < T::TN; ++j) b[j] = Ys[buf][kk * 4 + fk][wn0 + j * 16 + fr];
+                    for (int j = 0; j < T::TN; ++j) b[s][u][j] = Ys[buf][(k0 + u) * 4 + fk][wn0 + j * 16 + fr];
+                }
+            };
+            rd(0, 0);
 #pragma unroll
-                for (int i = 0; i < T::TM; ++i)
+            for (int bt = 0; bt < NB; ++bt) {
+                if (bt + 1 < NB) rd((bt + 1) & 1, (bt + 1) * 4);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < T::TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-                    }
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < T::TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[bt & 1][u][i], b[bt & 1][u][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -680,6 +725,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, in
         float sum = 0.f;
         if (ci < Cin && col_ok) {
             const float* src = slab + (size_t)(tap * Kp + ci) * slabN + co0 + tx;
+#pragma unroll 8
             for (int k = 0; k < splits; ++k) sum += src[(size_t)k * split_stride];
         }
         lds[tx * stride + r * taps + tap] = sum;
@@ -767,7 +813,13 @@ inline bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
     tile = pick_tile(d, Mlin);
     int BM, BN;
     tile_dims(tile, BM, BN);
-    if (d->mode == MCAV_G_ADJ_STRIDE2) {
+    p.groups = d->groups > 1 ? d->groups : 1;
+    if (p.groups > 1) {
+        if ((d->mode != MCAV_G_DIRECT && d->mode != MCAV_G_SMALLC) || d->pool || d->B % p.groups != 0) return false;
+        p.Mc = (int)(Mlin / p.groups);
+        p.McP = round_up(p.Mc, BM);
+        p.M = p.groups * p.McP;
+    } else if (d->mode == MCAV_G_ADJ_STRIDE2) {
         p.Mc = d->B * ((d->Hd + 1) / 2) * ((d->Wd + 1) / 2);
         p.McP = round_up(p.Mc, BM);
         p.M = 4 * p.McP;
@@ -867,13 +919,15 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     p.splits = (p.Mpix + p.pix_per_split - 1) / p.pix_per_split;
     p.want_bias = d->dbias != nullptr;
     pl.slab_bytes = align_up(sizeof(float) * (size_t)p.splits * (p.Ktot + 1) * p.slabN, 256);
-    pl.groups = p.splits > 16 ? 16 : 0;                          // two-level reduction above 16 splits
+    pl.groups = p.splits > 8 ? 8 : 0;                            // two-level reduction above 8 splits
     pl.per_group = pl.groups ? (p.splits + pl.groups - 1) / pl.groups : 0;
     if (pl.groups) pl.groups = (p.splits + pl.per_group - 1) / pl.per_group;
     pl.pre_bytes = align_up(sizeof(float) * (size_t)pl.groups * (p.Ktot + 1) * p.slabN, 256);
-    int ci_t = 480 / p.taps;                                     // 32 x (CI_T * taps + 1) floats of LDS <= 64 KB
-    if (ci_t > 32) ci_t = 32;
-    if (ci_t >= 16) ci_t = ci_t / 16 * 16; else if (ci_t >= 8) ci_t = 8; else if (ci_t < 1) return false;
+    int ci_t = 32;                                               // 32 x (CI_T * taps + 1) floats of LDS <= 64 KB ...
+    while (ci_t > 1 && ci_t * p.taps > 480) ci_t >>= 1;
+    if (ci_t * p.taps > 480) return false;
+    const int co_tiles = (d->Cout + 31) / 32;                    // ... and enough blocks to fill the chip
+    while (ci_t > 1 && co_tiles * ((d->Cin + ci_t - 1) / ci_t) < 256) ci_t >>= 1;
     pl.ci_t = ci_t;
     return true;
 }
@@ -883,7 +937,7 @@ inline void launch_wgrad(const WgradParams& p, hipStream_t s) {
     const int grid = p.splits * p.mtiles * p.ntiles;
     const int wave_ch = T::BM / 4;          // channels one wavefront's A columns span
     const bool fast = p.g.mode == MCAV_G_DIRECT && (p.g.C1 & 3) == 0 && (p.g.C2 & 3) == 0 && (p.g.C2 == 0 || p.g.C1 % wave_ch == 0) &&
-                      (p.Cout & 3) == 0 && (p.Cdy & 3) == 0 && (p.dy_choff & 3) == 0;
+                      (p.Cout & 3) == 0 && (p.Cdy & 3) == 0 && (p.dy_choff & 3) == 0 && p.Wd >= 16;
     if (fast) wgrad_kernel<T, K_FAST><<<grid, 256, 0, s>>>(p);
     else wgrad_kernel<T, K_GENERIC><<<grid, 256, 0, s>>>(p);
 }

@@ -32,33 +32,37 @@ __global__ void nhwc_to_nchw_kernel(const float* src, int B, int C, int H, int W
 // stats: [mtiles][2][C] per-tile sums of x and x^2 (from the conv epilogue).  32 channels x 8 tile-slices per block.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, int mtiles, int C, double count, const float* gamma, const float* beta,
                                                           float eps, float momentum, float* running_mean, float* running_var, float* scale,
-                                                          float* shift, float* save_mean, float* save_invstd) {
+                                                          float* shift, float* save_mean, float* save_invstd, int groups) {
     __shared__ double s1[8][32], s2[8][32];
     const int cl = threadIdx.x & 31, part = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
-    double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int t = part; t < mtiles; t += 8) {
-            a += (double)stats[((size_t)t * 2 + 0) * C + c];
-            b += (double)stats[((size_t)t * 2 + 1) * C + c];
+    for (int g = 0; g < groups; ++g) {          // groups are finalised in order: running statistics see pass 0, then pass 1, ...
+        const float* st = stats + (size_t)g * mtiles * 2 * C;
+        double a = 0.0, b = 0.0;
+        if (c < C)
+            for (int t = part; t < mtiles; t += 8) {
+                a += (double)st[((size_t)t * 2 + 0) * C + c];
+                b += (double)st[((size_t)t * 2 + 1) * C + c];
+            }
+        s1[part][cl] = a; s2[part][cl] = b;
+        __syncthreads();
+        if (part == 0 && c < C) {
+            for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+            const double mean = a / count;
+            double var = b / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = gamma[c] * invstd;
+            scale[g * C + c] = sc;
+            shift[g * C + c] = beta[c] - (float)mean * sc;
+            save_mean[g * C + c] = (float)mean;
+            save_invstd[g * C + c] = invstd;
+            if (running_mean) {
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+                running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
         }
-    s1[part][cl] = a; s2[part][cl] = b;
-    __syncthreads();
-    if (part == 0 && c < C) {
-        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
-        const double mean = a / count;
-        double var = b / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
-        scale[c] = sc;
-        shift[c] = beta[c] - (float)mean * sc;
-        save_mean[c] = (float)mean;
-        save_invstd[c] = invstd;
-        if (running_mean) {
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
-            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
+        __syncthreads();
     }
 }
 
@@ -70,9 +74,10 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
     shift[c] = beta[c] - rm[c] * sc;
 }
 
-__global__ __launch_bounds__(256) void bn_apply_kernel(const f32x4* x, const f32x4* scale, const f32x4* shift, const f32x4* res, int relu, size_t n4, int C4, f32x4* y) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(const f32x4* x, const f32x4* scale, const f32x4* shift, const f32x4* res, int relu, size_t n4, int C4, f32x4* y,
+                                                       size_t group4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4);
+        const int c = (int)(i % C4) + (int)(i / group4) * C4;
         f32x4 v = x[i] * scale[c] + shift[c];
         if (res) v += res[i];
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -88,8 +93,13 @@ __device__ __forceinline__ f32x4 relu_mask(f32x4 g, f32x4 y) {
 // Per-block partial sums of dz and dz * xhat.  G = C/4 channel groups; a block covers PL = 256 / min(G,256) pixel lanes.
 constexpr int BNR_BLOCKS = 256;
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* dy, const f32x4* yact, const f32x4* x, const f32x4* mean, const f32x4* invstd,
-                                                            int relu, size_t n_pix, int C4, float* part /* [blocks][2][C] */) {
+                                                            int relu, size_t n_pix /* per group */, int C4, float* part /* [groups][blocks][2][C] */) {
     __shared__ f32x4 sh[2][256];
+    const int grp = blockIdx.y;
+    dy += (size_t)grp * n_pix * C4; x += (size_t)grp * n_pix * C4;
+    if (yact) yact += (size_t)grp * n_pix * C4;
+    mean += (size_t)grp * C4; invstd += (size_t)grp * C4;
+    part += (size_t)grp * gridDim.x * 2 * C4 * 4;
     const size_t per = (n_pix + gridDim.x - 1) / gridDim.x;
     const size_t pb = (size_t)blockIdx.x * per, pe = pb + per < n_pix ? pb + per : n_pix;
     for (int g0 = 0; g0 < C4; g0 += 256) {
@@ -120,37 +130,47 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* dy, con
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, float* dgamma, float* dbeta, int accumulate, float* sums) {
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, float* dgamma, float* dbeta, int accumulate, float* sums,
+                                                              int groups) {
     __shared__ double s1[8][32], s2[8][32];
     const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
-    double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int k = slice; k < nblk; k += 8) {
-            a += (double)part[(size_t)k * 2 * C + c];
-            b += (double)part[(size_t)k * 2 * C + C + c];
+    double ta = 0.0, tb = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        const float* pg = part + (size_t)g * nblk * 2 * C;
+        double a = 0.0, b = 0.0;
+        if (c < C)
+            for (int k = slice; k < nblk; k += 8) {
+                a += (double)pg[(size_t)k * 2 * C + c];
+                b += (double)pg[(size_t)k * 2 * C + C + c];
+            }
+        s1[slice][cl] = a; s2[slice][cl] = b;
+        __syncthreads();
+        if (slice == 0 && c < C) {
+            for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+            sums[(size_t)g * 2 * C + c] = (float)a;
+            sums[(size_t)g * 2 * C + C + c] = (float)b;
+            ta += a; tb += b;
         }
-    s1[slice][cl] = a; s2[slice][cl] = b;
-    __syncthreads();
+        __syncthreads();
+    }
     if (slice == 0 && c < C) {
-        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
-        sums[c] = (float)a;
-        sums[C + c] = (float)b;
-        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
-        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)ta : (float)ta;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)tb : (float)tb;
     }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* dy, const f32x4* yact, const f32x4* x, const f32x4* gamma, const f32x4* mean,
                                                            const f32x4* invstd, const f32x4* sums, int relu, size_t n4, int C4, float inv_count,
-                                                           f32x4* dx, f32x4* dres, int dres_acc) {
+                                                           f32x4* dx, f32x4* dres, int dres_acc, size_t group4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4);
+        const int c = (int)(i % C4), grp = (int)(i / group4);
         f32x4 g = dy[i];
         if (relu) g = relu_mask(g, yact[i]);
         if (dres) dres[i] = dres_acc ? dres[i] + g : g;
-        const f32x4 is = invstd[c];
-        const f32x4 xh = (x[i] - mean[c]) * is;
-        dx[i] = (gamma[c] * is) * (g - sums[c] * inv_count - xh * (sums[C4 + c] * inv_count));
+        const f32x4 is = invstd[grp * C4 + c];
+        const f32x4 xh = (x[i] - mean[grp * C4 + c]) * is;
+        const f32x4* sg = sums + (size_t)grp * 2 * C4;
+        dx[i] = (gamma[c] * is) * (g - sg[c] * inv_count - xh * (sg[C4 + c] * inv_count));
     }
 }
 
@@ -295,11 +315,12 @@ MCAV_EXPORT int mcav_nhwc_to_nchw(const float* src, int B, int C, int H, int W, 
 
 MCAV_EXPORT int mcav_bn_finalize(const float* stats, int mtiles, int C, double count, const float* gamma, const float* beta, float eps, float momentum,
                                  float* running_mean, float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
-                                 void* stream) {
+                                 int groups, void* stream) {
+    if (groups < 1) groups = 1;
     if (!stats || !gamma || !beta || !scale || !shift || !save_mean || !save_invstd || mtiles <= 0 || C <= 0 || count <= 0) return MCAV_E_INVALID;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MCAV_E_INVALID;
     bn_finalize_kernel<<<(C + 31) / 32, 256, 0, as_stream(stream)>>>(stats, mtiles, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale,
-                                                                      shift, save_mean, save_invstd);
+                                                                      shift, save_mean, save_invstd, groups);
     return launch_status();
 }
 
@@ -311,47 +332,53 @@ MCAV_EXPORT int mcav_bn_eval_coeffs(const float* gamma, const float* beta, const
 }
 
 MCAV_EXPORT int mcav_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, int act, size_t n_pix, int C, float* y,
-                              void* stream) {
+                              size_t pix_per_group, void* stream) {
     if (!x || !scale || !shift || !y || C <= 0 || (C & 3) || (act != MCAV_ACT_NONE && act != MCAV_ACT_RELU)) return MCAV_E_INVALID;
     if (n_pix == 0) return MCAV_OK;
     const size_t n4 = n_pix * (size_t)(C / 4);
     bn_apply_kernel<<<grid_for(n4), 256, 0, as_stream(stream)>>>((const f32x4*)x, (const f32x4*)scale, (const f32x4*)shift, (const f32x4*)residual,
-                                                                 act == MCAV_ACT_RELU, n4, C / 4, (f32x4*)y);
+                                                                 act == MCAV_ACT_RELU, n4, C / 4, (f32x4*)y,
+                                                                 (pix_per_group ? pix_per_group : n_pix) * (size_t)(C / 4));
     return launch_status();
 }
 
-MCAV_EXPORT size_t mcav_bn_bwd_workspace_bytes(size_t n_pix, int C) {
+MCAV_EXPORT size_t mcav_bn_bwd_workspace_bytes(size_t n_pix, int C, int groups) {
     (void)n_pix;
-    return C > 0 ? align_up(sizeof(float) * 2 * (size_t)C * BNR_BLOCKS, 256) : 0;
+    if (groups < 1) groups = 1;
+    return C > 0 ? align_up(sizeof(float) * 2 * (size_t)C * BNR_BLOCKS * groups, 256) : 0;
 }
 
 MCAV_EXPORT int mcav_bn_bwd_reduce(const float* dy, const float* y_act, const float* x, const float* save_mean, const float* save_invstd, int relu,
-                                   size_t n_pix, int C, float* dgamma, float* dbeta, int accumulate, float* sums, void* workspace,
+                                   size_t n_pix, int C, float* dgamma, float* dbeta, int accumulate, float* sums, int groups, void* workspace,
                                    size_t workspace_bytes, void* stream) {
-    if (!dy || !x || !save_mean || !save_invstd || !sums || !workspace || C <= 0 || (C & 3) || n_pix == 0) return MCAV_E_INVALID;
+    if (groups < 1) groups = 1;
+    if (!dy || !x || !save_mean || !save_invstd || !sums || !workspace || C <= 0 || (C & 3) || n_pix == 0 || n_pix % groups) return MCAV_E_INVALID;
     if (relu && !y_act) return MCAV_E_INVALID;
     const int C4 = C / 4;
     if (C4 < 256 && (256 % C4) != 0) return MCAV_E_INVALID;
     if (C4 > 256 && (C4 % 256) != 0) return MCAV_E_INVALID;
-    if (workspace_bytes < mcav_bn_bwd_workspace_bytes(n_pix, C)) return MCAV_E_WORKSPACE;
-    int blocks = (int)((n_pix + 31) / 32 < (size_t)BNR_BLOCKS ? (n_pix + 31) / 32 : (size_t)BNR_BLOCKS);
+    if (workspace_bytes < mcav_bn_bwd_workspace_bytes(n_pix, C, groups)) return MCAV_E_WORKSPACE;
+    const size_t pg = n_pix / groups;
+    int blocks = (int)((pg + 31) / 32 < (size_t)BNR_BLOCKS ? (pg + 31) / 32 : (size_t)BNR_BLOCKS);
     float* part = reinterpret_cast<float*>(workspace);
     hipStream_t s = as_stream(stream);
-    bn_bwd_reduce_kernel<<<blocks, 256, 0, s>>>((const f32x4*)dy, (const f32x4*)y_act, (const f32x4*)x, (const f32x4*)save_mean, (const f32x4*)save_invstd,
-                                                relu, n_pix, C4, part);
-    bn_bwd_finalize_kernel<<<(C + 31) / 32, 256, 0, s>>>(part, blocks, C, dgamma, dbeta, accumulate, sums);
+    bn_bwd_reduce_kernel<<<dim3(blocks, groups), 256, 0, s>>>((const f32x4*)dy, (const f32x4*)y_act, (const f32x4*)x, (const f32x4*)save_mean,
+                                                              (const f32x4*)save_invstd, relu, pg, C4, part);
+    bn_bwd_finalize_kernel<<<(C + 31) / 32, 256, 0, s>>>(part, blocks, C, dgamma, dbeta, accumulate, sums, groups);
     return launch_status();
 }
 
 MCAV_EXPORT int mcav_bn_bwd_apply(const float* dy, const float* y_act, const float* x, const float* gamma, const float* save_mean,
                                   const float* save_invstd, const float* sums, int relu, size_t n_pix, int C, float* dx, float* dres,
-                                  int dres_accumulate, void* stream) {
-    if (!dy || !x || !gamma || !save_mean || !save_invstd || !sums || !dx || C <= 0 || (C & 3) || n_pix == 0) return MCAV_E_INVALID;
+                                  int dres_accumulate, int groups, void* stream) {
+    if (groups < 1) groups = 1;
+    if (!dy || !x || !gamma || !save_mean || !save_invstd || !sums || !dx || C <= 0 || (C & 3) || n_pix == 0 || n_pix % groups) return MCAV_E_INVALID;
     if (relu && !y_act) return MCAV_E_INVALID;
     const size_t n4 = n_pix * (size_t)(C / 4);
     bn_bwd_apply_kernel<<<grid_for(n4), 256, 0, as_stream(stream)>>>((const f32x4*)dy, (const f32x4*)y_act, (const f32x4*)x, (const f32x4*)gamma,
                                                                      (const f32x4*)save_mean, (const f32x4*)save_invstd, (const f32x4*)sums, relu, n4,
-                                                                     C / 4, (float)(1.0 / (double)n_pix), (f32x4*)dx, (f32x4*)dres, dres_accumulate);
+                                                                     C / 4, (float)(1.0 / (double)(n_pix / groups)), (f32x4*)dx, (f32x4*)dres, dres_accumulate,
+                                                                     (n_pix / groups) * (size_t)(C / 4));
     return launch_status();
 }
 

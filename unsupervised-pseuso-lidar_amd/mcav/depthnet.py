@@ -26,12 +26,12 @@ def hw(t):
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm'd conv
-def conv_bn(conv, bn, x, stride, pad, train, relu, residual=None, smallc=False):
-    """-> (raw conv output, BN state, activated output)"""
+def conv_bn(conv, bn, x, stride, pad, train, relu, residual=None, smallc=False, groups=1):
+    """-> (raw conv output, BN state, activated output).  groups: independent passes stacked along the batch (per-pass statistics)."""
     spec = spec_of(conv, stride, pad, N.PAD_ZERO, smallc)
     if train:
-        raw, slab = N.conv_fwd(spec, x, stats=True)
-        st = N.bn_train_coeffs(bn, slab, raw.shape[0] * raw.shape[1] * raw.shape[2])
+        raw, slab = N.conv_fwd(spec, x, stats=True, groups=groups)
+        st = N.bn_train_coeffs(bn, slab, raw.shape[0] * raw.shape[1] * raw.shape[2] // groups, groups)
     else:
         raw = N.conv_fwd(spec, x)
         st = N.bn_eval_coeffs(bn)
@@ -39,14 +39,14 @@ def conv_bn(conv, bn, x, stride, pad, train, relu, residual=None, smallc=False):
 
 
 # ------------------------------------------------------------------------------------------------ BasicBlock
-def block_forward(blk, x, stride, train):
+def block_forward(blk, x, stride, train, groups=1):
     sv = {"x": x, "stride": stride}
-    sv["r1"], sv["st1"], sv["h1"] = conv_bn(blk.conv1, blk.bn1, x, stride, 1, train, True)
+    sv["r1"], sv["st1"], sv["h1"] = conv_bn(blk.conv1, blk.bn1, x, stride, 1, train, True, groups=groups)
     if blk.downsample is not None:
-        sv["rd"], sv["std"], idt = conv_bn(blk.downsample[0], blk.downsample[1], x, stride, 0, train, False)
+        sv["rd"], sv["std"], idt = conv_bn(blk.downsample[0], blk.downsample[1], x, stride, 0, train, False, groups=groups)
     else:
         idt = x
-    sv["r2"], sv["st2"], sv["out"] = conv_bn(blk.conv2, blk.bn2, sv["h1"], 1, 1, train, True, residual=idt)
+    sv["r2"], sv["st2"], sv["out"] = conv_bn(blk.conv2, blk.bn2, sv["h1"], 1, 1, train, True, residual=idt, groups=groups)
     return sv["out"], sv
 
 
@@ -74,17 +74,17 @@ def block_backward(blk, sv, dout, addend=None):
 STAGES = ("layer1", "layer2", "layer3", "layer4")
 
 
-def encoder_forward(net, x4, train):
-    """net: ResNetParams holder; x4: NHWC4 image.  -> ([f0..f4], saved)"""
+def encoder_forward(net, x4, train, groups=1):
+    """net: ResNetParams holder; x4: NHWC4 image (groups passes stacked along the batch).  -> ([f0..f4], saved)"""
     sv = {"x4": x4}
-    sv["c1"], sv["st"], f0 = conv_bn(net.conv1, net.bn1, x4, 2, 3, train, True, smallc=True)
+    sv["c1"], sv["st"], f0 = conv_bn(net.conv1, net.bn1, x4, 2, 3, train, True, smallc=True, groups=groups)
     p0, sv["idx"] = N.maxpool_fwd(f0)
     feats, blocks = [f0], []
     x = p0
     for si, name in enumerate(STAGES):
         stage_sv = []
         for bi, blk in enumerate(getattr(net, name)):
-            x, bsv = block_forward(blk, x, 2 if (si > 0 and bi == 0) else 1, train)
+            x, bsv = block_forward(blk, x, 2 if (si > 0 and bi == 0) else 1, train, groups)
             stage_sv.append(bsv)
         blocks.append(stage_sv)
         feats.append(x)

@@ -23,7 +23,7 @@ class IgemmDesc(ctypes.Structure):
                 ("mode", c_i), ("stride", c_i), ("sign", c_i), ("offset", c_i), ("pad_mode", c_i),
                 ("y", c_p), ("Hd", c_i), ("Wd", c_i), ("Cd", c_i), ("n_begin", c_i), ("n_count", c_i), ("y_choff", c_i),
                 ("bias", c_p), ("act", c_i), ("dact_aux", c_p), ("dact", c_i), ("addend", c_p), ("pool", c_i), ("stats", c_p),
-                ("tile", c_i)]
+                ("tile", c_i), ("groups", c_i)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -42,12 +42,12 @@ L.register({
     "mcav_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "mcav_nchw_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "mcav_nhwc_to_nchw": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
-    "mcav_bn_finalize": (c_i, [c_p, c_i, c_i, c_d, c_p, c_p, c_f, c_f] + [c_p] * 7),
+    "mcav_bn_finalize": (c_i, [c_p, c_i, c_i, c_d, c_p, c_p, c_f, c_f] + [c_p] * 6 + [c_i, c_p]),
     "mcav_bn_eval_coeffs": (c_i, [c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p]),
-    "mcav_bn_apply": (c_i, [c_p, c_p, c_p, c_p, c_i, c_sz, c_i, c_p, c_p]),
-    "mcav_bn_bwd_workspace_bytes": (c_sz, [c_sz, c_i]),
-    "mcav_bn_bwd_reduce": (c_i, [c_p] * 5 + [c_i, c_sz, c_i, c_p, c_p, c_i, c_p, c_p, c_sz, c_p]),
-    "mcav_bn_bwd_apply": (c_i, [c_p] * 7 + [c_i, c_sz, c_i, c_p, c_p, c_i, c_p]),
+    "mcav_bn_apply": (c_i, [c_p, c_p, c_p, c_p, c_i, c_sz, c_i, c_p, c_sz, c_p]),
+    "mcav_bn_bwd_workspace_bytes": (c_sz, [c_sz, c_i, c_i]),
+    "mcav_bn_bwd_reduce": (c_i, [c_p] * 5 + [c_i, c_sz, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_sz, c_p]),
+    "mcav_bn_bwd_apply": (c_i, [c_p] * 7 + [c_i, c_sz, c_i, c_p, c_p, c_i, c_i, c_p]),
     "mcav_maxpool3s2_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     "mcav_maxpool3s2_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "mcav_act_bwd": (c_i, [c_p, c_p, c_i, c_sz, c_p, c_i, c_p]),
@@ -144,7 +144,7 @@ def out_size(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
 
-def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0):
+def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0, groups=1):
     """y = act(conv(cat(up2?(x1), x2)) + bias).  x1/x2 NHWC.  Returns y, or (y, stats_slab, mtiles) when stats."""
     B = x1.shape[0]
     Hs, Ws = (x1.shape[1] * 2, x1.shape[2] * 2) if up1 else (x1.shape[1], x1.shape[2])
@@ -162,6 +162,7 @@ def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0):
     d.y, d.Hd, d.Wd, d.Cd, d.n_begin, d.n_count, d.y_choff = P(y), Hd, Wd, spec.cout, 0, spec.cout, 0
     d.bias, d.act = P(spec.bias), act
     d.tile = tile
+    d.groups = groups if stats else 1
     h = L.lib()
     slab = None
     if stats:
@@ -249,19 +250,21 @@ def grad_buffer(param):
 # ------------------------------------------------------------------------------------------------ BatchNorm
 class BNState:
     """Per-call saved tensors of one train-mode BatchNorm."""
-    __slots__ = ("scale", "shift", "mean", "invstd")
+    __slots__ = ("scale", "shift", "mean", "invstd", "groups")
 
 
-def bn_train_coeffs(bn, slab, count):
-    """bn: holder with weight, bias, running_mean, running_var, num_batches_tracked, eps, momentum."""
+def bn_train_coeffs(bn, slab, count, groups=1):
+    """bn: holder with weight, bias, running_mean, running_var, num_batches_tracked, eps, momentum.
+    count: pixels per group.  groups > 1: per-group statistics, running stats updated once per group in order."""
     C = bn.weight.shape[0]
     st = BNState()
-    buf = empty((4, C), bn.weight)
+    buf = empty((4, groups, C), bn.weight)
     st.scale, st.shift, st.mean, st.invstd = buf[0], buf[1], buf[2], buf[3]
-    L.check(L.lib().mcav_bn_finalize(P(slab), slab.shape[0], C, float(count), P(bn.weight), P(bn.bias), bn.eps, bn.momentum,
-                                     P(bn.running_mean), P(bn.running_var), P(st.scale), P(st.shift), P(st.mean), P(st.invstd), L.stream()),
-            "mcav_bn_finalize")
-    bn.num_batches_tracked += 1
+    st.groups = groups
+    L.check(L.lib().mcav_bn_finalize(P(slab), slab.shape[0] // groups, C, float(count), P(bn.weight), P(bn.bias), bn.eps, bn.momentum,
+                                     P(bn.running_mean), P(bn.running_var), P(st.scale), P(st.shift), P(st.mean), P(st.invstd), groups,
+                                     L.stream()), "mcav_bn_finalize")
+    bn.num_batches_tracked += groups
     return st
 
 
@@ -270,6 +273,7 @@ def bn_eval_coeffs(bn):
     st = BNState()
     buf = empty((2, C), bn.weight)
     st.scale, st.shift, st.mean, st.invstd = buf[0], buf[1], None, None
+    st.groups = 1
     L.check(L.lib().mcav_bn_eval_coeffs(P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var), bn.eps, C, P(st.scale), P(st.shift),
                                         L.stream()), "mcav_bn_eval_coeffs")
     return st
@@ -278,8 +282,9 @@ def bn_eval_coeffs(bn):
 def bn_apply(x, st, relu, residual=None):
     y = torch.empty_like(x)
     C = x.shape[-1]
-    L.check(L.lib().mcav_bn_apply(P(x), P(st.scale), P(st.shift), P(residual), ACT_RELU if relu else ACT_NONE, x.numel() // C, C, P(y), L.stream()),
-            "mcav_bn_apply")
+    n_pix = x.numel() // C
+    L.check(L.lib().mcav_bn_apply(P(x), P(st.scale), P(st.shift), P(residual), ACT_RELU if relu else ACT_NONE, n_pix, C, P(y),
+                                  n_pix // st.groups, L.stream()), "mcav_bn_apply")
     return y
 
 
@@ -288,17 +293,18 @@ def bn_backward(bn, st, dy, y_act, x, relu, want_dres=False, dres_out=None, dres
     C = x.shape[-1]
     n_pix = x.numel() // C
     h = L.lib()
-    ws = L.workspace(h.mcav_bn_bwd_workspace_bytes(n_pix, C), x.device, "bn_bwd")
-    sums = empty((2, C), x)
+    G = st.groups
+    ws = L.workspace(h.mcav_bn_bwd_workspace_bytes(n_pix, C, G), x.device, "bn_bwd")
+    sums = empty((G, 2, C), x)
     gg, gb = grad_buffer(bn.weight), grad_buffer(bn.bias)
-    L.check(h.mcav_bn_bwd_reduce(P(dy), P(y_act), P(x), P(st.mean), P(st.invstd), int(relu), n_pix, C, P(gg), P(gb), 1, P(sums), P(ws), ws.numel(),
-                                 L.stream()), "mcav_bn_bwd_reduce")
+    L.check(h.mcav_bn_bwd_reduce(P(dy), P(y_act), P(x), P(st.mean), P(st.invstd), int(relu), n_pix, C, P(gg), P(gb), 1, P(sums), G, P(ws),
+                                 ws.numel(), L.stream()), "mcav_bn_bwd_reduce")
     dx = torch.empty_like(x)
     dres = None
     if want_dres:
         dres = dres_out if dres_out is not None else torch.empty_like(x)
     L.check(h.mcav_bn_bwd_apply(P(dy), P(y_act), P(x), P(bn.weight), P(st.mean), P(st.invstd), P(sums), int(relu), n_pix, C, P(dx), P(dres),
-                                int(dres_accumulate), L.stream()), "mcav_bn_bwd_apply")
+                                int(dres_accumulate), G, L.stream()), "mcav_bn_bwd_apply")
     return (dx, dres) if want_dres else dx
 
 

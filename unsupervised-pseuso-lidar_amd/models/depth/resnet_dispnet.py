@@ -166,6 +166,37 @@ class _DispResNetFn(torch.autograd.Function):
         return (None, None) + (None,) * len(list(mod.parameters()))
 
 
+class _DispResNetPairFn(torch.autograd.Function):
+    """Two independent passes (e.g. tgt and ref0, trainer.py:296-299) as ONE set of launches over the stacked batch.
+
+    BatchNorm statistics stay per pass (the conv epilogue's statistic tiles never straddle a pass; running statistics are
+    updated pass 0 first, then pass 1), so the result equals two separate calls, at half the launches and twice the rows per GEMM."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, mod, *params):
+        x4 = torch.cat([_to_nhwc4(xa), _to_nhwc4(xb)], 0)
+        feats, esv = E.encoder_forward(mod.encoder.encoder, x4, mod.training, groups=2)
+        disps, dsv = E.decoder_forward(mod.decoder, feats, (0,))
+        ctx.mod, ctx.esv, ctx.dsv = mod, esv, dsv
+        d = disps[0]
+        d = d.view(d.shape[0], 1, d.shape[1], d.shape[2])
+        B = xa.shape[0]
+        return d[:B], d[B:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        mod = ctx.mod
+        if ga is None or gb is None:
+            ref = ga if ga is not None else gb
+            ga = torch.zeros_like(ref) if ga is None else ga
+            gb = torch.zeros_like(ref) if gb is None else gb
+        g = torch.cat([L.dev(ga.contiguous(), "grad"), L.dev(gb.contiguous(), "grad")], 0)
+        dfe = E.decoder_backward(mod.decoder, ctx.dsv, {0: g.view(g.shape[0], g.shape[2], g.shape[3], 1)})
+        E.encoder_backward(mod.encoder.encoder, ctx.esv, dfe)
+        ctx.esv = ctx.dsv = None
+        return (None, None, None) + (None,) * len(list(mod.parameters()))
+
+
 class DispResNet(nn.Module):
     def __init__(self):
         super().__init__()
@@ -174,3 +205,8 @@ class DispResNet(nn.Module):
 
     def forward(self, x):
         return [_DispResNetFn.apply(x, self, *self.parameters())]
+
+    def forward_pair(self, xa, xb):
+        """== (self(xa), self(xb)) evaluated in that order, as one stacked launch set (see _DispResNetPairFn)."""
+        da, db = _DispResNetPairFn.apply(xa, xb, self, *self.parameters())
+        return [da], [db]

@@ -159,7 +159,10 @@ class Trainer:
         ref_imgs = [img.to(dev, non_blocking=True) for img in samples['ref_imgs']]
         intrinsics = samples['intrinsics'].to(dev, non_blocking=True)
         gt = samples['groundtruth']
-        disps = [self.depth_model(image_t) for image_t in (tgt, ref_imgs[0])]     # two separate passes, as the reference
+        if hasattr(self.depth_model, "forward_pair"):
+            disps = list(self.depth_model.forward_pair(tgt, ref_imgs[0]))          # == two separate passes (per-pass BN statistics)
+        else:
+            disps = [self.depth_model(image_t) for image_t in (tgt, ref_imgs[0])]  # two separate passes, as the reference
         if semi_sup_pose:
             poses = torch.cat((samples["oxts"][0].unsqueeze(1), samples["oxts"][1].unsqueeze(1)), 1).to(dev)
         else:
