@@ -52,16 +52,25 @@ def build(device, lr=1e-4, seed=0):
     return depth, pose, opt, Losses()
 
 
-def make_step(depth, pose, opt, crit, samples, pair=True):
+def make_step(depth, pose, opt, crit, samples, pair=True, graph=False):
     from mcav import dist as mdist
     tgt, refs, K = samples["tgt"], samples["ref_imgs"], samples["intrinsics"]
 
-    def step():
+    def fwd_bwd(tgt, ref0, ref1, K):
         opt.zero_grad()
-        disps = list(depth.forward_pair(tgt, refs[0])) if pair else [depth(tgt), depth(refs[0])]
-        poses = pose(tgt, refs)
-        loss = crit.forward(tgt, refs, disps, poses, K, None)
+        disps = list(depth.forward_pair(tgt, ref0)) if pair else [depth(tgt), depth(ref0)]
+        poses = pose(tgt, [ref0, ref1])
+        loss = crit.forward(tgt, [ref0, ref1], disps, poses, K, None)
         sum(loss).backward()
+        return tuple(loss)
+
+    runner = fwd_bwd
+    if graph:
+        from mcav.graph import GraphedForwardBackward
+        runner = GraphedForwardBackward(fwd_bwd, opt.arena(), [tgt, refs[0], refs[1], K])
+
+    def step():
+        loss = runner(tgt, refs[0], refs[1], K)
         opt.grad_scale = mdist.allreduce_gradients(opt.arena())
         opt.step()
         return loss
@@ -100,6 +109,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--separate-passes", action="store_true", help="run the two depth passes as separate launch sets (default: stacked)")
+    ap.add_argument("--graph", action="store_true", help="replay forward+backward as one captured hipGraph")
     ap.add_argument("--layer-report", default=None, help="write a per-launch table of the instrumented step to this file")
     args = ap.parse_args()
 
@@ -116,7 +126,8 @@ def main():
     mdist.broadcast_parameters(opt.arena())
     s = synthetic_samples(B, H, W, rank)
     samples = {"tgt": s["tgt"].to(device), "ref_imgs": [r.to(device) for r in s["ref_imgs"]], "intrinsics": s["intrinsics"].to(device)}
-    step = make_step(depth, pose, opt, crit, samples, pair=not args.separate_passes)
+    step = make_step(depth, pose, opt, crit, samples, pair=not args.separate_passes, graph=args.graph)
+    eager_step = step if not args.graph else make_step(depth, pose, opt, crit, samples, pair=not args.separate_passes, graph=False)
 
     def fence():
         if world > 1:
@@ -153,7 +164,7 @@ def main():
         N.PROFILE_LOSS = []
         N.PROFILE_TAGS = [] if args.layer_report else None
         for _ in range(3):
-            step()
+            eager_step()                      # instrumented launches must be issued eagerly (events are not graph nodes)
         torch.cuda.synchronize()
         recs, N.PROFILE = N.PROFILE, None
         if args.layer_report:

@@ -134,6 +134,8 @@ int mcav_maxpool3s2_bwd(const float* dy, const uint8_t* idx, int B, int H, int W
 
 /* elementwise helpers on flat buffers */
 int mcav_act_bwd(const float* dy, const float* y, int act, size_t n, float* dx, int accumulate, void* stream);
+/* dx[i * stride] = dy[i] * act'(y[i]): a 1-channel gradient map written into channel 0 of a wider (pre-zeroed) NHWC tensor */
+int mcav_act_bwd_strided(const float* dy, const float* y, int act, size_t n, float* dx, int stride, void* stream);
 int mcav_add(const float* a, const float* b, size_t n, float* out, void* stream);
 /* out[b, c] = scale * mean over pixels of x[b, pix, c]  (PoseNet head: mean(3).mean(2) * 0.06), and its backward */
 int mcav_spatial_mean(const float* x, int B, int n_pix, int C, float scale, float* out, void* stream);

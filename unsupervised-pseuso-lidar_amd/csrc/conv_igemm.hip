@@ -35,6 +35,7 @@ using Tile256x32 = Tile<256, 32, 64, 32, 32>;
 using Tile256x16 = Tile<256, 16, 64, 16, 16>;
 using Tile128x128 = Tile<128, 128, 64, 64, 32>;
 using Tile64x16 = Tile<64, 16, 16, 16, 16>;
+using Tile128x32 = Tile<128, 32, 32, 32, 32>;
 
 struct IgemmParams {
     GatherSrc g;
@@ -167,14 +168,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     // ---- K-tile enumeration: (tap, chunk); ADJ_STRIDE2 tiles only visit the taps of their parity class
     const int nchunks = g.mode == MCAV_G_SMALLC ? 1 : p.Kp / CK;
     int cls_py = 0, cls_px = 0;
-    if (KIND == K_GENERIC && g.mode == MCAV_G_ADJ_STRIDE2) { const int cls = m0 / p.McP; cls_py = cls >> 1; cls_px = cls & 1; }
+    if (KIND != K_REFLADJ && g.mode == MCAV_G_ADJ_STRIDE2) { const int cls = m0 / p.McP; cls_py = cls >> 1; cls_px = cls & 1; }
     auto tap_ok = [&](int tap) -> bool {
-        if (KIND != K_GENERIC || g.mode != MCAV_G_ADJ_STRIDE2) return true;
+        if (KIND == K_REFLADJ || g.mode != MCAV_G_ADJ_STRIDE2) return true;
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
         return (((cls_py + g.offset - ky) | (cls_px + g.offset - kx)) & 1) == 0;
     };
     int T_total;
-    if (KIND == K_GENERIC && g.mode == MCAV_G_SMALLC) {
+    if (KIND != K_REFLADJ && g.mode == MCAV_G_SMALLC) {
         T_total = (p.taps * 4 + CK - 1) / CK;
     } else {
         int nv = 0;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         T_total = nv * nchunks;
     }
     int tap = 0, chunk = 0;
-    if (!(KIND == K_GENERIC && g.mode == MCAV_G_SMALLC)) while (tap < p.taps && !tap_ok(tap)) ++tap;
+    if (!(KIND != K_REFLADJ && g.mode == MCAV_G_SMALLC)) while (tap < p.taps && !tap_ok(tap)) ++tap;
 
     // ---- cached per-row source BYTE offsets of the current tap (K_FAST / K_REFLADJ); OOB = reads as zero
     unsigned o1[T::AROWS], o2[T::AROWS];
@@ -199,13 +200,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(g.C2 > 0 ? g.x2 : g.x1, g.C2 > 0 ? bytes2 : 0u);
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, (unsigned)((size_t)(p.n_begin + p.n_count) * p.Kstride * 4));
     auto refresh_offsets = [&]() {
-        if (KIND == K_GENERIC) return;
+        if (KIND == K_GENERIC || g.mode == MCAV_G_SMALLC) return;
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
 #pragma unroll
         for (int j = 0; j < T::AROWS; ++j) {
             int sy, sx;
             bool ok = rn[j] >= 0;
-            if (KIND == K_FAST) {
+            if (KIND == K_FAST && g.mode == MCAV_G_ADJ_STRIDE2) {
+                const int ty = ry[j] + g.offset - ky, tx = rx[j] + g.offset - kx;      // x[d] collects dy[(d + pad - k) / 2] when whole
+                ok = ok && ty >= 0 && tx >= 0 && (((ty | tx) & 1) == 0);
+                sy = ty >> 1; sx = tx >> 1;
+            } else if (KIND == K_FAST) {
                 sy = ry[j] * g.stride + g.sign * ky + g.offset;
                 sx = rx[j] * g.stride + g.sign * kx + g.offset;
                 if (g.pad_mode == MCAV_PAD_REFLECT) {
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
     auto load_tile = [&](f32x4 (&ra)[T::AROWS], f32x4 (&rb)[T::BVECS]) {      // global -> registers for the tile at (tap, chunk)
         int ky, kx, c, kflat;
-        if (KIND == K_GENERIC && g.mode == MCAV_G_SMALLC) {
+        if (KIND != K_REFLADJ && g.mode == MCAV_G_SMALLC) {
             const int t4 = chunk * 4 + c4;             // every 16-byte column is its own tap
             ky = t4 / p.kw; kx = t4 - ky * p.kw; c = 0; kflat = chunk * CK;
             if (t4 >= p.taps) ky = -1;
@@ -240,6 +245,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (rn[j] >= 0 && ky >= 0) v = gather4(g, rn[j], ry[j], rx[j], ky, kx, c);
                 ra[j] = v;
+            }
+        } else if (KIND == K_FAST && g.mode == MCAV_G_SMALLC) {
+            // 4-channel image: one 16-byte load per (row, tap); zero padding = out-of-range offset
+#pragma unroll
+            for (int j = 0; j < T::AROWS; ++j) {
+                const int sy = ry[j] * g.stride + ky + g.offset, sx = rx[j] * g.stride + kx + g.offset;
+                const bool ok = rn[j] >= 0 && ky >= 0 && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
+                ra[j] = buf_load4(rs1, ok ? (unsigned)(((rn[j] * g.Hs + sy) * g.Ws + sx) * 4) * 4u : OOB);
             }
         } else {
             // the whole 16-channel chunk lies in x1 or in x2 (C1 % 16 == 0 whenever there is an x2): wave-uniform choice
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         }
     };
     auto advance = [&]() {
-        if (KIND == K_GENERIC && g.mode == MCAV_G_SMALLC) { ++chunk; return; }
+        if (KIND != K_REFLADJ && g.mode == MCAV_G_SMALLC) { ++chunk; return; }
         if (++chunk == nchunks) {
             chunk = 0;
             do { ++tap; } while (tap < p.taps && !tap_ok(tap));
@@ -446,6 +459,7 @@ struct WgradParams {
     int kh, kw, Kp, taps, Ktot;   // Ktot = taps * Kp (GEMM rows)
     const float* dy;
     int Hd, Wd, Cdy, dy_choff, Cout;
+    int CoutLoad;                  // Cout rounded up to 4 when dy physically has those (zero) channels
     int Mpix;                      // B * Hd * Wd
     int splits, pix_per_split;     // pixel ranges per workgroup (multiple of KP)
     int mtiles, ntiles;
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
             const int m = pb + pl;
             if constexpr (KIND == K_FAST) {
                 const int c = n0 + bcol * 4;
-                const bool ok = pl < KP && m < pix_end && c + 4 <= p.Cout;
+                const bool ok = pl < KP && m < pix_end && c + 4 <= p.CoutLoad;
                 rb[j] = buf_load4(rsy, ok ? (unsigned)(m * p.Cdy + p.dy_choff + c) * 4u : OOB);
                 continue;
             }
@@ -784,6 +798,7 @@ inline void tile_dims(int id, int& BM, int& BN) {
         case 3: BM = 256; BN = 32; break;
         case 4: BM = 256; BN = 16; break;
         case 5: BM = 128; BN = 128; break;
+        case 7: BM = 128; BN = 32; break;
         default: BM = 64; BN = 16; break;
     }
 }
@@ -837,7 +852,8 @@ template <class T>
 inline void launch_igemm(const IgemmParams& p, hipStream_t s) {
     const bool c4ok = (p.g.C1 & 3) == 0 && (p.g.C2 & 3) == 0 && (p.g.C2 == 0 || (p.g.C1 & 15) == 0);
     const int grid = p.mtiles * p.ntiles;
-    if (p.g.mode == MCAV_G_DIRECT && c4ok) igemm_kernel<T, K_FAST><<<grid, 256, 0, s>>>(p);
+    const bool fast_mode = p.g.mode == MCAV_G_DIRECT || (p.g.mode == MCAV_G_ADJ_STRIDE2 && p.g.C2 == 0) || p.g.mode == MCAV_G_SMALLC;
+    if (fast_mode && c4ok) igemm_kernel<T, K_FAST><<<grid, 256, 0, s>>>(p);
     else if (p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0) igemm_kernel<T, K_REFLADJ><<<grid, 256, 0, s>>>(p);
     else igemm_kernel<T, K_GENERIC><<<grid, 256, 0, s>>>(p);
 }
@@ -865,6 +881,7 @@ MCAV_EXPORT int mcav_igemm(const mcav_igemm_desc* d, void* stream) {
         case 4: launch_igemm<Tile256x16>(p, s); break;
         case 5: launch_igemm<Tile128x128>(p, s); break;
         case 6: launch_igemm<Tile64x16>(p, s); break;
+        case 7: launch_igemm<Tile128x32>(p, s); break;
         default: return MCAV_E_INVALID;
     }
     return launch_status();
@@ -892,6 +909,7 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     p.g.mode = d->mode; p.g.stride = d->stride; p.g.sign = d->sign; p.g.offset = d->offset; p.g.pad_mode = d->pad_mode;
     p.kh = d->kh; p.kw = d->kw; p.Kp = d->Kp; p.taps = d->kh * d->kw; p.Ktot = p.taps * d->Kp;
     p.dy = d->dy; p.Hd = d->Hd; p.Wd = d->Wd; p.Cdy = d->Cdy; p.dy_choff = d->dy_choff; p.Cout = d->Cout;
+    p.CoutLoad = round_up(d->Cout, 4) <= d->Cdy - d->dy_choff ? round_up(d->Cout, 4) : d->Cout;
     const long M = (long)d->B * d->Hd * d->Wd;
     if (M > 0x7fffffffL) return false;
     if ((long)d->B * d->Hs * d->Ws * (d->C1 > d->C2 ? d->C1 : d->C2) * 4 >= 0x7fffffffL || M * d->Cdy * 4 >= 0x7fffffffL) return false;
@@ -900,10 +918,10 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     int tile = d->tile;
     if (!tile) {
         if (d->Cout <= 16) tile = round_up(p.Ktot, 64) < round_up(p.Ktot, 256) ? 6 : 4;
-        else if (d->Cout <= 32) tile = 3;
+        else if (d->Cout <= 32) tile = (d->C2 > 0 && d->C1 % 64 != 0) ? 7 : 3;
         else tile = p.Ktot <= 64 ? 2 : 1;
     }
-    if (tile != 1 && tile != 2 && tile != 3 && tile != 4 && tile != 6) return false;
+    if (tile != 1 && tile != 2 && tile != 3 && tile != 4 && tile != 6 && tile != 7) return false;
     pl.tile = tile;
     int BM, BN;
     tile_dims(tile, BM, BN);
@@ -936,8 +954,8 @@ template <class T>
 inline void launch_wgrad(const WgradParams& p, hipStream_t s) {
     const int grid = p.splits * p.mtiles * p.ntiles;
     const int wave_ch = T::BM / 4;          // channels one wavefront's A columns span
-    const bool fast = p.g.mode == MCAV_G_DIRECT && (p.g.C1 & 3) == 0 && (p.g.C2 & 3) == 0 && (p.g.C2 == 0 || p.g.C1 % wave_ch == 0) &&
-                      (p.Cout & 3) == 0 && (p.Cdy & 3) == 0 && (p.dy_choff & 3) == 0 && p.Wd >= 16;
+    const bool fast = (p.g.mode == MCAV_G_DIRECT || p.g.mode == MCAV_G_SMALLC) && (p.g.C1 & 3) == 0 && (p.g.C2 & 3) == 0 && (p.g.C2 == 0 || p.g.C1 % wave_ch == 0) &&
+                      (p.CoutLoad & 3) == 0 && (p.Cdy & 3) == 0 && (p.dy_choff & 3) == 0 && p.Wd >= 16;
     if (fast) wgrad_kernel<T, K_FAST><<<grid, 256, 0, s>>>(p);
     else wgrad_kernel<T, K_GENERIC><<<grid, 256, 0, s>>>(p);
 }
@@ -962,6 +980,7 @@ MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t wor
         case 3: launch_wgrad<Tile256x32>(pl.p, s); break;
         case 4: launch_wgrad<Tile256x16>(pl.p, s); break;
         case 6: launch_wgrad<Tile64x16>(pl.p, s); break;
+        case 7: launch_wgrad<Tile128x32>(pl.p, s); break;
         default: return MCAV_E_INVALID;
     }
     const dim3 rgrid((d->Cout + 31) / 32, (d->Cin + pl.ci_t - 1) / pl.ci_t);

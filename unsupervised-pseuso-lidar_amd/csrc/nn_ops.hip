@@ -260,6 +260,11 @@ __global__ void act_bwd_kernel(const float* dy, const float* y, int act, size_t 
     }
 }
 
+__global__ void act_bwd_strided_kernel(const float* dy, const float* y, int act, size_t n, float* dx, int stride) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dx[i * stride] = dy[i] * dact(y[i], act);
+}
+
 __global__ void add_kernel(const float* a, const float* b, size_t n, float* out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
 }
@@ -400,6 +405,13 @@ MCAV_EXPORT int mcav_act_bwd(const float* dy, const float* y, int act, size_t n,
     if (!dy || !y || !dx) return MCAV_E_INVALID;
     if (n == 0) return MCAV_OK;
     act_bwd_kernel<<<grid_for(n), 256, 0, as_stream(stream)>>>(dy, y, act, n, dx, accumulate);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_act_bwd_strided(const float* dy, const float* y, int act, size_t n, float* dx, int stride, void* stream) {
+    if (!dy || !y || !dx || stride < 1) return MCAV_E_INVALID;
+    if (n == 0) return MCAV_OK;
+    act_bwd_strided_kernel<<<grid_for(n), 256, 0, as_stream(stream)>>>(dy, y, act, n, dx, stride);
     return launch_status();
 }
 

@@ -137,7 +137,8 @@ def decoder_backward(dec, sv, ddisp, need_feature_grads=True):
         s10 = dec_spec(dec.conv("upconv", i, 0).conv.conv)
         if i in ddisp and ddisp[i] is not None:
             sd = dec_spec(dec.conv("dispconv", i).conv)
-            dpre_d = N.act_bwd(ddisp[i], sv["disp"][i], N.ACT_SIGMOID)
+            # sigmoid'(disp) * d disp, stored as channel 0 of a zeroed 4-channel map so the 16-byte gathers apply
+            dpre_d = N.act_bwd_padded(ddisp[i], sv["disp"][i], N.ACT_SIGMOID, 4)
             N.conv_wgrad(sd, b, dpre_d)
             # d b_i from the disparity head, through ELU'(b_i); joins what came from level i-1 (addend)
             dpre_b = N.conv_dgrad(sd, dpre_d, hw(b), dact_aux=b, dact=N.ACT_ELU, addend=dpre_b)

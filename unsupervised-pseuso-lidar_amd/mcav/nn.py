@@ -51,6 +51,7 @@ L.register({
     "mcav_maxpool3s2_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     "mcav_maxpool3s2_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "mcav_act_bwd": (c_i, [c_p, c_p, c_i, c_sz, c_p, c_i, c_p]),
+    "mcav_act_bwd_strided": (c_i, [c_p, c_p, c_i, c_sz, c_p, c_i, c_p]),
     "mcav_add": (c_i, [c_p, c_p, c_sz, c_p, c_p]),
     "mcav_spatial_mean": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "mcav_spatial_mean_bwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
@@ -190,7 +191,7 @@ def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=N
     y = out if out is not None else empty((B, Hs // 2 if pool else Hs, Ws // 2 if pool else Ws, n_count), dy)
     d = IgemmDesc()
     d.x1, d.x2 = P(dy), None
-    d.B, d.Hs, d.Ws, d.C1, d.C2, d.up1 = B, Hd, Wd, Cout, 0, 0
+    d.B, d.Hs, d.Ws, d.C1, d.C2, d.up1 = B, Hd, Wd, Cout, 0, 0       # Cout = channels physically in dy (may be zero-padded past spec.cout)
     d.w = P(wb)
     d.kh, d.kw, d.Np, d.Kp = spec.kh, spec.kw, up16(spec.cin), up16(spec.cout)
     if spec.stride == 1:
@@ -207,7 +208,7 @@ def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=N
     d.bias, d.act = None, ACT_NONE
     d.dact_aux, d.dact, d.addend, d.pool = P(dact_aux), dact, P(addend), int(pool)
     d.tile = tile
-    with _Timed("dgrad", 2.0 * B * Hd * Wd * Cout * n_count * spec.kh * spec.kw,
+    with _Timed("dgrad", 2.0 * B * Hd * Wd * spec.cout * n_count * spec.kh * spec.kw,
                 "M=%d N=%d K=%dx%d s%d mode%d pool%d %dx%d" % (B * Hs * Ws, n_count, Cout, spec.kh * spec.kw, spec.stride, d.mode, int(pool), Hs, Ws)):
         L.check(L.lib().mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(dgrad)")
     return y
@@ -348,6 +349,15 @@ def act_bwd(dy, y, act, out=None, accumulate=False):
         out = torch.empty_like(y)
         accumulate = False
     L.check(L.lib().mcav_act_bwd(P(dy), P(y), act, y.numel(), P(out), int(accumulate), L.stream()), "mcav_act_bwd")
+    return out
+
+
+def act_bwd_padded(dy, y, act, cp):
+    """dy * act'(y) for a 1-channel map, written to channel 0 of a zeroed [B,H,W,cp] tensor."""
+    B, H, W, C = y.shape
+    assert C == 1
+    out = torch.zeros((B, H, W, cp), dtype=torch.float32, device=y.device)
+    L.check(L.lib().mcav_act_bwd_strided(P(dy), P(y), act, y.numel(), P(out), cp, L.stream()), "mcav_act_bwd_strided")
     return out
 
 
