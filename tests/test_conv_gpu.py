@@ -49,6 +49,11 @@ CASES = [
     (2, 6, 10, 96, 32, 3, 1, 1, 1, 2, 0),       # Cin = 96 (decoder (1,1))
     (2, 6, 10, 32, 16, 3, 1, 1, 1, 2, 6),       # tile 64x16
     (2, 6, 10, 32, 32, 3, 1, 1, 1, 2, 3),       # tile 256x32
+    (2, 6, 10, 32, 32, 3, 1, 1, 1, 2, 7),       # tile 128x32
+    (2, 12, 20, 64, 64, 3, 1, 1, 0, 1, 8),      # 32-deep K-tiles, 128x64
+    (2, 12, 20, 128, 128, 3, 1, 1, 1, 2, 9),    # 32-deep K-tiles, 128x128, reflection pad
+    (1, 10, 18, 64, 128, 3, 2, 1, 0, 0, 10),    # 32-deep K-tiles, 64x64, stride 2 (and its parity-class adjoint)
+    (2, 6, 10, 96, 32, 3, 1, 1, 1, 2, 10),      # Cin = 96 with 32-deep K-tiles
 ]
 
 
@@ -75,10 +80,11 @@ def test_conv_fwd_dgrad_wgrad(case):
     dyd = nhwc(dy)
     dx = N.conv_dgrad(spec, dyd, (H, W), tile=tile)
     assert rel_err(nchw(dx, Cin), x.grad) < 2e-5
-    N.conv_wgrad(spec, xin, dyd)
+    wt = tile if tile in (1, 2, 3, 4, 6, 7) else 0
+    N.conv_wgrad(spec, xin, dyd, tile=wt)
     assert rel_err(wp.grad, w.grad) < 5e-5
     assert rel_err(bp.grad, b.grad) < 5e-5
-    N.conv_wgrad(spec, xin, dyd)                     # accumulates
+    N.conv_wgrad(spec, xin, dyd, tile=wt)            # accumulates
     assert rel_err(wp.grad, 2 * w.grad) < 5e-5
 
 

@@ -16,17 +16,21 @@
 
 namespace mcav {
 
-template <int BM_, int BN_, int WM_, int WN_, int MF_>
+template <int BM_, int BN_, int WM_, int WN_, int MF_, int CK_ = 16>
 struct Tile {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, MF = MF_;
+    static constexpr int KD = CK_;                            // K-tile depth of the forward/dgrad kernel (channels of one tap)
+    static constexpr int LD = CK_ + 4;                        // LDS row stride: 20 or 36 floats, both conflict-free for ds_read_b128
+    static constexpr int LPR = CK_ / 4;                       // lanes (16-byte columns) per operand row
+    static constexpr int RPP = 256 / LPR;                     // rows loaded per pass of the 256 threads
     static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
     static constexpr int TM = WM / MF, TN = WN / MF;         // MFMA tiles per wavefront
     static constexpr int ACC = MF == 32 ? 16 : 4;             // accumulator registers per MFMA tile
     using AccT = typename std::conditional<MF_ == 32, f32x16, f32x4>::type;
-    static constexpr int AROWS = BM / 64;                     // A rows per thread per K-tile (4 lanes per row)
-    static constexpr int BVECS = (BN * 4 + 255) / 256;        // B float4 per thread per K-tile
+    static constexpr int AROWS = BM / RPP;                    // A rows per thread per K-tile
+    static constexpr int BVECS = (BN * LPR + 255) / 256;      // B float4 per thread per K-tile
     static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per workgroup");
-    static_assert(BM % 64 == 0, "BM multiple of 64");
+    static_assert(BM % RPP == 0, "BM multiple of the rows per pass");
 };
 
 using Tile128x64 = Tile<128, 64, 64, 32, 32>;
@@ -36,6 +40,9 @@ using Tile256x16 = Tile<256, 16, 64, 16, 16>;
 using Tile128x128 = Tile<128, 128, 64, 64, 32>;
 using Tile64x16 = Tile<64, 16, 16, 16, 16>;
 using Tile128x32 = Tile<128, 32, 32, 32, 32>;
+using Tile128x64k32 = Tile<128, 64, 64, 32, 32, 32>;      // 32-deep K-tiles: twice the MFMA work per barrier / per load round trip
+using Tile128x128k32 = Tile<128, 128, 64, 64, 32, 32>;
+using Tile64x64k32 = Tile<64, 64, 32, 32, 32, 32>;
 
 struct IgemmParams {
     GatherSrc g;
@@ -136,8 +143,9 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned by
 template <class T, int KIND>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     constexpr int BM = T::BM, BN = T::BN;
-    __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDK];
+    constexpr int CK = T::KD;
+    __shared__ __attribute__((aligned(16))) float As[2][BM][T::LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][T::LD];
     __shared__ int s_out[BM];
     __shared__ float s_stat[T::WAVES_M][2][BN];
 
@@ -147,13 +155,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const int m0 = mt * BM, n0 = nt * BN;
     const GatherSrc& g = p.g;
 
-    // ---- per-thread A rows (4 lanes per row: c4 = 16-byte column of the 16-float K chunk)
-    const int c4 = tid & 3, r0 = tid >> 2;
+    // ---- per-thread A rows (LPR lanes per row: c4 = 16-byte column of the CK-float K chunk)
+    const int c4 = tid % T::LPR, r0 = tid / T::LPR;
     int rn[T::AROWS], ry[T::AROWS], rx[T::AROWS];
 #pragma unroll
     for (int j = 0; j < T::AROWS; ++j) {
         int n, dy, dx;
-        const bool ok = decode_row(p, m0 + r0 + 64 * j, n, dy, dx);
+        const bool ok = decode_row(p, m0 + r0 + T::RPP * j, n, dy, dx);
         rn[j] = ok ? n : -1; ry[j] = dy; rx[j] = dx;
     }
     // ---- epilogue table: destination pixel index of every tile row
@@ -289,18 +297,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         }
 #pragma unroll
         for (int j = 0; j < T::BVECS; ++j) {
-            const int e = tid + 256 * j, nn = e >> 2;
+            const int e = tid + 256 * j, nn = e / T::LPR, cb = e % T::LPR;
             const bool ok = nn < BN && n0 + nn < p.n_count;
-            rb[j] = buf_load4(rsw, ok ? (unsigned)(((p.n_begin + n0 + nn) * p.Kstride + kflat + (e & 3) * 4) * 4) : OOB);
+            rb[j] = buf_load4(rsw, ok ? (unsigned)(((p.n_begin + n0 + nn) * p.Kstride + kflat + cb * 4) * 4) : OOB);
         }
     };
     auto store_tile = [&](const f32x4 (&ra)[T::AROWS], const f32x4 (&rb)[T::BVECS], int buf) {
 #pragma unroll
-        for (int j = 0; j < T::AROWS; ++j) *reinterpret_cast<f32x4*>(&As[buf][r0 + 64 * j][c4 * 4]) = ra[j];
+        for (int j = 0; j < T::AROWS; ++j) *reinterpret_cast<f32x4*>(&As[buf][r0 + T::RPP * j][c4 * 4]) = ra[j];
 #pragma unroll
         for (int j = 0; j < T::BVECS; ++j) {
-            const int e = tid + 256 * j, nn = e >> 2;
-            if (nn < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nn][(e & 3) * 4]) = rb[j];
+            const int e = tid + 256 * j, nn = e / T::LPR, cb = e % T::LPR;
+            if (nn < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nn][cb * 4]) = rb[j];
         }
     };
     auto advance = [&]() {
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         if constexpr (T::MF == 32) {
             const int frow = lane & 31, fk = (lane >> 5) * 4;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < CK / 8; ++ks) {
                 f32x4 a[T::TM], b[T::TN];
 #pragma unroll
                 for (int i = 0; i < T::TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][wm0 + i * 32 + frow][ks * 8 + fk]);
@@ -342,18 +350,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             }
         } else {
             const int frow = lane & 15, fk = (lane >> 4) * 4;
-            f32x4 a[T::TM], b[T::TN];
 #pragma unroll
-            for (int i = 0; i < T::TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][wm0 + i * 16 + frow][fk]);
+            for (int ks = 0; ks < CK / 16; ++ks) {
+                f32x4 a[T::TM], b[T::TN];
 #pragma unroll
-            for (int j = 0; j < T::TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][wn0 + j * 16 + frow][fk]);
+                for (int i = 0; i < T::TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][wm0 + i * 16 + frow][ks * 16 + fk]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+                for (int j = 0; j < T::TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][wn0 + j * 16 + frow][ks * 16 + fk]);
 #pragma unroll
-                for (int i = 0; i < T::TM; ++i)
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int j = 0; j < T::TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < T::TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -785,10 +796,11 @@ inline int pick_tile(const mcav_igemm_desc* d, long M) {
     if (d->tile) return d->tile;
     if (d->n_count <= 16) return M >= 256 * 64 ? 4 : 6;
     if (d->n_count <= 32) return 3;
+    // measured on MI355X (tools/conv_bench.py): small output tiles with 32-deep K-tiles win at every layer shape of the step --
+    // more co-resident workgroups hide the load round trips, and a 32-deep tile halves the barriers per FLOP
+    if (d->mode != MCAV_G_SMALLC && d->Kp % 32 == 0) return 10;
     const long t128x64 = ((M + 127) / 128) * ((d->n_count + 63) / 64);
-    if (d->n_count >= 128 && ((M + 127) / 128) * ((d->n_count + 127) / 128) >= 512) return 5;
-    if (t128x64 >= 384) return 1;
-    return 2;
+    return t128x64 >= 1024 ? 1 : 2;
 }
 
 inline void tile_dims(int id, int& BM, int& BN) {
@@ -799,6 +811,9 @@ inline void tile_dims(int id, int& BM, int& BN) {
         case 4: BM = 256; BN = 16; break;
         case 5: BM = 128; BN = 128; break;
         case 7: BM = 128; BN = 32; break;
+        case 8: BM = 128; BN = 64; break;
+        case 9: BM = 128; BN = 128; break;
+        case 10: BM = 64; BN = 64; break;
         default: BM = 64; BN = 16; break;
     }
 }
@@ -826,6 +841,7 @@ inline bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
     if ((long)d->B * d->Hs * d->Ws * (d->C1 > d->C2 ? d->C1 : d->C2) * 4 >= 0x7fffffffL) return false;   // 32-bit byte offsets
     if ((long)d->Np * kstride_of(d->kh * d->kw, d->Kp) * 4 >= 0x7fffffffL) return false;
     tile = pick_tile(d, Mlin);
+    if (tile >= 8 && tile <= 10 && (d->mode == MCAV_G_SMALLC || d->Kp % 32 != 0)) return false;      // 32-deep K-tiles need Kp % 32 == 0
     int BM, BN;
     tile_dims(tile, BM, BN);
     p.groups = d->groups > 1 ? d->groups : 1;
@@ -882,6 +898,9 @@ MCAV_EXPORT int mcav_igemm(const mcav_igemm_desc* d, void* stream) {
         case 5: launch_igemm<Tile128x128>(p, s); break;
         case 6: launch_igemm<Tile64x16>(p, s); break;
         case 7: launch_igemm<Tile128x32>(p, s); break;
+        case 8: launch_igemm<Tile128x64k32>(p, s); break;
+        case 9: launch_igemm<Tile128x128k32>(p, s); break;
+        case 10: launch_igemm<Tile64x64k32>(p, s); break;
         default: return MCAV_E_INVALID;
     }
     return launch_status();
@@ -919,7 +938,7 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     if (!tile) {
         if (d->Cout <= 16) tile = round_up(p.Ktot, 64) < round_up(p.Ktot, 256) ? 6 : 4;
         else if (d->Cout <= 32) tile = (d->C2 > 0 && d->C1 % 64 != 0) ? 7 : 3;
-        else tile = p.Ktot <= 64 ? 2 : 1;
+        else tile = 2;            // 64x64 beats 128x64 on every layer shape of the step (tools/conv_bench.py wgrad)
     }
     if (tile != 1 && tile != 2 && tile != 3 && tile != 4 && tile != 6 && tile != 7) return false;
     pl.tile = tile;
