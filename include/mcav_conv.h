@@ -141,6 +141,21 @@ int mcav_add(const float* a, const float* b, size_t n, float* out, void* stream)
 int mcav_spatial_mean(const float* x, int B, int n_pix, int C, float scale, float* out, void* stream);
 int mcav_spatial_mean_bwd(const float* dout, int B, int n_pix, int C, float scale, float* dx, void* stream);
 
+/* --- helpers of the secondary networks (DispNetS: models/depth/disp_net.py:97-141; PoseFc: models/pose/pose_fc.py:63-84) and of the
+ * multi-scale loss (losses.py:212-216) --- */
+/* dst[p, doff + c] (+)= src[p, soff + c] for c < C: channel concat / slice between NHWC tensors of pixel strides Cs and Cd */
+int mcav_copy_channels(const float* src, size_t n_pix, int Cs, int soff, float* dst, int Cd, int doff, int C, int accumulate, void* stream);
+/* F.interpolate(mode='bilinear', align_corners=False) on 1-channel maps [B, h, w] -> [B, H, W], and its adjoint (gather form).
+ * scale_y/x = source step per output pixel; 0 means h/H, w/W (size given); 0.5 = scale_factor 2 followed by a crop to H x W */
+int mcav_resize_bilinear_fwd(const float* src, int B, int h, int w, float* dst, int H, int W, float scale_y, float scale_x, void* stream);
+int mcav_resize_bilinear_bwd(const float* ddst, int B, int h, int w, float* dsrc, int H, int W, float scale_y, float scale_x, int accumulate,
+                             void* stream);
+int mcav_affine(const float* x, float a, float b, size_t n, float* y, void* stream);      /* y = a x + b */
+int mcav_mul(const float* a, const float* b, size_t n, float* y, void* stream);          /* y = a * b */
+/* out[c] (+)= sum over pixels of x[p, c]  (bias gradient of ConvTranspose2d) */
+size_t mcav_colsum_workspace_bytes(int C);
+int mcav_colsum(const float* x, size_t n_pix, int C, float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad) over one flat arena.
  * step is the 1-based step count AFTER this update.  grad_scale multiplies the gradient first (1/world_size for DP). */
 int mcav_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,

@@ -26,18 +26,24 @@ SHAPES = [
 ]
 
 
-def timeit(fn, n=20):
+def timeit(fn, n=7, inner=25):
+    """Median over n samples of (time of `inner` back-to-back launches) / inner.
+
+    Several launches per sample keep the GPU queue full: a single ~50 us kernel between two events would mostly measure
+    the host's enqueue latency (torch.empty + ctypes), not the kernel."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
     ts = []
     for _ in range(n):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()                                  # something in the queue before the first event
         e0.record()
-        fn()
+        for _ in range(inner):
+            fn()
         e1.record()
         torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        ts.append(e0.elapsed_time(e1) / inner)
     ts.sort()
     return ts[len(ts) // 2]
 
@@ -47,7 +53,7 @@ def main():
     tiles = [0]
     for a in sys.argv[2:]:
         if a.startswith("--tiles"):
-            tiles = [int(t) for t in a.split("=")[1].split(",")]
+            tiles = [int(t, 0) for t in a.split("=")[1].split(",")]
     dev = "cuda"
     for (B, H, W, Cin, Cout, k, s, p, pm) in SHAPES:
         w = torch.nn.Parameter(torch.randn(Cout, Cin, k, k, device=dev) * 0.05)

@@ -1,0 +1,183 @@
+// Small HBM-bound helpers used by the secondary networks (DispNetS, PoseFc) and the multi-scale loss:
+// channel copy (concat / slice), bilinear resize of 1-channel maps (align_corners = False) and its adjoint,
+// affine map, elementwise product, per-channel column sums.
+#include "conv_gather.h"
+
+namespace mcav {
+
+inline int aux_grid(size_t n, int cap = 4096) {
+    size_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b < (size_t)cap ? b : (size_t)cap);
+}
+
+__global__ void copy_channels_kernel(const float* src, size_t n_pix, int Cs, int soff, float* dst, int Cd, int doff, int C, int accumulate) {
+    const size_t total = n_pix * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / C;
+        const int c = (int)(i - p * C);
+        const float v = src[p * Cs + soff + c];
+        float* d = dst + p * Cd + doff + c;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+// PyTorch's bilinear source index with align_corners = False: max(0, scale * (dst + 0.5) - 0.5)
+__device__ __forceinline__ void bil_src(int o, float scale, int n_in, int& i0, int& i1, float& lam) {
+    float s = scale * ((float)o + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    lam = s - (float)i0;
+}
+
+__global__ void resize_bilinear_fwd_kernel(const float* src, int B, int h, int w, float* dst, int H, int W, float sy, float sx) {
+    const size_t total = (size_t)B * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % W);
+        const int oy = (int)((i / W) % H);
+        const int b = (int)(i / ((size_t)W * H));
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bil_src(oy, sy, h, y0, y1, ly);
+        bil_src(ox, sx, w, x0, x1, lx);
+        const float* p = src + (size_t)b * h * w;
+        const float top = p[y0 * w + x0] * (1.f - lx) + p[y0 * w + x1] * lx;
+        const float bot = p[y1 * w + x0] * (1.f - lx) + p[y1 * w + x1] * lx;
+        dst[i] = top * (1.f - ly) + bot * ly;
+    }
+}
+
+// adjoint as a gather: every source pixel collects from the destination pixels whose taps touch it (fixed order)
+__global__ void resize_bilinear_bwd_kernel(const float* ddst, int B, int h, int w, float* dsrc, int H, int W, float sy, float sx, int accumulate) {
+    const size_t total = (size_t)B * h * w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ix = (int)(i % w);
+        const int iy = (int)((i / w) % h);
+        const int b = (int)(i / ((size_t)w * h));
+        int oy_lo = (int)floorf(((float)iy - 0.5f) / sy - 0.5f) - 1, oy_hi = (int)ceilf(((float)iy + 1.5f) / sy - 0.5f) + 1;
+        int ox_lo = (int)floorf(((float)ix - 0.5f) / sx - 0.5f) - 1, ox_hi = (int)ceilf(((float)ix + 1.5f) / sx - 0.5f) + 1;
+        if (iy == 0) oy_lo = 0;          // the clamp max(0, .) maps a run of leading outputs onto source 0
+        if (ix == 0) ox_lo = 0;
+        oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+        oy_hi = oy_hi > H - 1 ? H - 1 : oy_hi; ox_hi = ox_hi > W - 1 ? W - 1 : ox_hi;
+        if (iy == h - 1) oy_hi = H - 1;
+        if (ix == w - 1) ox_hi = W - 1;
+        const float* g = ddst + (size_t)b * H * W;
+        float acc = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1;
+            float ly;
+            bil_src(oy, sy, h, y0, y1, ly);
+            float wy = 0.f;
+            if (y0 == iy) wy += 1.f - ly;
+            if (y1 == iy) wy += ly;
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1;
+                float lx;
+                bil_src(ox, sx, w, x0, x1, lx);
+                float wx = 0.f;
+                if (x0 == ix) wx += 1.f - lx;
+                if (x1 == ix) wx += lx;
+                if (wx != 0.f) acc += wy * wx * g[(size_t)oy * W + ox];
+            }
+        }
+        dsrc[i] = accumulate ? dsrc[i] + acc : acc;
+    }
+}
+
+__global__ void affine_kernel(const float* x, float a, float b, size_t n, float* y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = a * x[i] + b;
+}
+
+__global__ void mul_kernel(const float* a, const float* b, size_t n, float* y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = a[i] * b[i];
+}
+
+constexpr int CS_BLOCKS = 128;
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* x, size_t n_pix, int C, float* part) {
+    const size_t per = (n_pix + gridDim.x - 1) / gridDim.x;
+    const size_t pb = (size_t)blockIdx.x * per, pe = pb + per < n_pix ? pb + per : n_pix;
+    // thread (c, lane): lanes stride over pixels; consecutive threads read consecutive channels (coalesced)
+    const int Cc = C < 256 ? C : 256, PL = 256 / Cc;
+    __shared__ float sh[256];
+    for (int c0 = 0; c0 < C; c0 += Cc) {
+        const int c = c0 + (int)(threadIdx.x % Cc), pl = threadIdx.x / Cc;
+        float s = 0.f;
+        if (pl < PL && c < C)
+            for (size_t m = pb + pl; m < pe; m += PL) s += x[m * C + c];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < Cc && c0 + (int)threadIdx.x < C) {
+            float t = 0.f;
+            for (int k = 0; k < PL; ++k) t += sh[threadIdx.x + k * Cc];
+            part[(size_t)blockIdx.x * C + c0 + threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void colsum_final_kernel(const float* part, int nblk, int C, float* out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+}  // namespace mcav
+
+using namespace mcav;
+
+MCAV_EXPORT int mcav_copy_channels(const float* src, size_t n_pix, int Cs, int soff, float* dst, int Cd, int doff, int C, int accumulate, void* stream) {
+    if (!src || !dst || C <= 0 || soff < 0 || doff < 0 || soff + C > Cs || doff + C > Cd) return MCAV_E_INVALID;
+    if (n_pix == 0) return MCAV_OK;
+    copy_channels_kernel<<<aux_grid(n_pix * C), 256, 0, as_stream(stream)>>>(src, n_pix, Cs, soff, dst, Cd, doff, C, accumulate);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_resize_bilinear_fwd(const float* src, int B, int h, int w, float* dst, int H, int W, float scale_y, float scale_x, void* stream) {
+    if (!src || !dst || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return MCAV_E_INVALID;
+    const float sy = scale_y > 0.f ? scale_y : (float)h / (float)H, sx = scale_x > 0.f ? scale_x : (float)w / (float)W;
+    resize_bilinear_fwd_kernel<<<aux_grid((size_t)B * H * W), 256, 0, as_stream(stream)>>>(src, B, h, w, dst, H, W, sy, sx);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_resize_bilinear_bwd(const float* ddst, int B, int h, int w, float* dsrc, int H, int W, float scale_y, float scale_x, int accumulate,
+                                         void* stream) {
+    if (!ddst || !dsrc || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return MCAV_E_INVALID;
+    const float sy = scale_y > 0.f ? scale_y : (float)h / (float)H, sx = scale_x > 0.f ? scale_x : (float)w / (float)W;
+    if (sy > 1.f || sx > 1.f) return MCAV_E_INVALID;       // the gather-form adjoint assumes upsampling
+    resize_bilinear_bwd_kernel<<<aux_grid((size_t)B * h * w), 256, 0, as_stream(stream)>>>(ddst, B, h, w, dsrc, H, W, sy, sx, accumulate);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_affine(const float* x, float a, float b, size_t n, float* y, void* stream) {
+    if (!x || !y) return MCAV_E_INVALID;
+    if (n == 0) return MCAV_OK;
+    affine_kernel<<<aux_grid(n), 256, 0, as_stream(stream)>>>(x, a, b, n, y);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_mul(const float* a, const float* b, size_t n, float* y, void* stream) {
+    if (!a || !b || !y) return MCAV_E_INVALID;
+    if (n == 0) return MCAV_OK;
+    mul_kernel<<<aux_grid(n), 256, 0, as_stream(stream)>>>(a, b, n, y);
+    return launch_status();
+}
+
+MCAV_EXPORT size_t mcav_colsum_workspace_bytes(int C) { return C > 0 ? align_up(sizeof(float) * (size_t)CS_BLOCKS * C, 256) : 0; }
+
+MCAV_EXPORT int mcav_colsum(const float* x, size_t n_pix, int C, float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !out || !workspace || C <= 0 || n_pix == 0) return MCAV_E_INVALID;
+    if (C > 256 && C % 256 != 0) return MCAV_E_INVALID;
+    if (workspace_bytes < mcav_colsum_workspace_bytes(C)) return MCAV_E_WORKSPACE;
+    const int blocks = (int)(n_pix < (size_t)CS_BLOCKS ? n_pix : (size_t)CS_BLOCKS);
+    float* part = reinterpret_cast<float*>(workspace);
+    hipStream_t s = as_stream(stream);
+    colsum_part_kernel<<<blocks, 256, 0, s>>>(x, n_pix, C, part);
+    colsum_final_kernel<<<(C + 63) / 64, 64, 0, s>>>(part, blocks, C, out, accumulate);
+    return launch_status();
+}

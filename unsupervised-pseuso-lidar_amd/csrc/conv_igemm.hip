@@ -43,6 +43,7 @@ using Tile128x32 = Tile<128, 32, 32, 32, 32>;
 using Tile128x64k32 = Tile<128, 64, 64, 32, 32, 32>;      // 32-deep K-tiles: twice the MFMA work per barrier / per load round trip
 using Tile128x128k32 = Tile<128, 128, 64, 64, 32, 32>;
 using Tile64x64k32 = Tile<64, 64, 32, 32, 32, 32>;
+using Tile64x64k64 = Tile<64, 64, 32, 32, 32, 64>;       // 64-deep: 32 MFMAs per wavefront between barriers
 
 struct IgemmParams {
     GatherSrc g;
@@ -60,6 +61,7 @@ struct IgemmParams {
     int M;           // rows of the GEMM (incl. class / group padding)
     int Mc, McP;     // ADJ_STRIDE2: pixels per parity class and its BM-padded size; groups > 1: rows per group and padded size
     int groups;
+    int ablate;      // diagnostics only (tile | 0x100: issue every load out of range; tile | 0x200: skip the MFMAs)
     int mtiles, ntiles;
 };
 
@@ -136,6 +138,28 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, uns
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
 }
 
+// Hand-counted variant for the K_FAST main loop: the load is invisible to the compiler's s_waitcnt bookkeeping (which, across
+// the loop back-edge, would drain the youngest loads too), so tile t+2 can stay in flight while tile t+1 is written to LDS.
+// The destination registers must not be touched until the matching vm_wait<N>() below.
+__device__ __forceinline__ u32x4 make_rsrc_words(const void* ptr, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    u32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+
+__device__ __forceinline__ void asm_buf_load4(f32x4& v, u32x4 rsrc, unsigned byte_off) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(byte_off), "s"(rsrc) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
@@ -148,6 +172,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][T::LD];
     __shared__ int s_out[BM];
     __shared__ float s_stat[T::WAVES_M][2][BN];
+    // per-(tap, row) source byte offsets, computed once per workgroup (all the padding / reflection / stride / upsample logic
+    // lives here, outside the K loop).  fp32 MFMA shares the SIMD's FMA datapath with the VALU (equal rates), so every
+    // address instruction inside the loop is paid for in MFMA time: the loop keeps one v_add per load.
+    constexpr int MAXTAB = 9;
+    __shared__ unsigned s_o1[KIND == K_GENERIC ? 1 : MAXTAB][KIND == K_GENERIC ? 1 : BM];
+    __shared__ unsigned s_o2[KIND == K_GENERIC ? 1 : MAXTAB][KIND == K_GENERIC ? 1 : BM];
+    __shared__ int s_rn[KIND == K_GENERIC ? 1 : BM], s_ry[KIND == K_GENERIC ? 1 : BM], s_rx[KIND == K_GENERIC ? 1 : BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -171,6 +202,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         int o = -1;
         if (ok) o = p.pool ? ((n * (p.Hd >> 1) + (dy >> 1)) * (p.Wd >> 1) + (dx >> 1)) : ((n * p.Hd + dy) * p.Wd + dx);
         s_out[r] = o;
+        if (KIND != K_GENERIC) { s_rn[r] = ok ? n : -1; s_ry[r] = dy; s_rx[r] = dx; }
     }
 
     // ---- K-tile enumeration: (tap, chunk); ADJ_STRIDE2 tiles only visit the taps of their parity class
@@ -207,38 +239,70 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1, bytes1);
     const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(g.C2 > 0 ? g.x2 : g.x1, g.C2 > 0 ? bytes2 : 0u);
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, (unsigned)((size_t)(p.n_begin + p.n_count) * p.Kstride * 4));
+    const u32x4 ws1 = make_rsrc_words(g.x1, bytes1);
+    const u32x4 ws2 = make_rsrc_words(g.C2 > 0 ? g.x2 : g.x1, g.C2 > 0 ? bytes2 : 0u);
+    const u32x4 wsw = make_rsrc_words(p.w, (unsigned)((size_t)(p.n_begin + p.n_count) * p.Kstride * 4));
+    // source byte offsets (x1, x2) of destination pixel (n, dy, dx) under tap (ky, kx); OOB when the tap falls outside
+    auto src_offsets = [&](int n, int dy, int dx, int ky, int kx, unsigned& oa, unsigned& ob) {
+        int sy, sx;
+        bool ok = n >= 0;
+        if (KIND == K_FAST && g.mode == MCAV_G_ADJ_STRIDE2) {
+            const int ty = dy + g.offset - ky, tx = dx + g.offset - kx;      // x[d] collects dy[(d + pad - k) / 2] when whole
+            ok = ok && ty >= 0 && tx >= 0 && (((ty | tx) & 1) == 0);
+            sy = ty >> 1; sx = tx >> 1;
+        } else if (KIND == K_FAST) {
+            sy = dy * g.stride + g.sign * ky + g.offset;
+            sx = dx * g.stride + g.sign * kx + g.offset;
+            if (g.pad_mode == MCAV_PAD_REFLECT) {
+                sy = reflect_idx(sy, g.Hs);
+                sx = reflect_idx(sx, g.Ws);
+            }
+        } else {
+            sy = dy + 1 - ky;
+            sx = dx + 1 - kx;
+        }
+        ok = ok && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
+        const int pix = (n * g.Hs + sy) * g.Ws + sx;
+        const int pix1 = g.up1 ? ((n * (g.Hs >> 1) + (sy >> 1)) * (g.Ws >> 1) + (sx >> 1)) : pix;
+        oa = ok ? (unsigned)(pix1 * g.C1) * 4u : OOB;
+        ob = ok ? (unsigned)(pix * g.C2) * 4u : OOB;
+    };
+    const bool use_tab = KIND != K_GENERIC && g.mode != MCAV_G_SMALLC && p.taps <= MAXTAB;
+    if (use_tab) {
+        __syncthreads();                                   // s_rn / s_ry / s_rx are complete
+        for (int e = tid; e < p.taps * BM; e += 256) {
+            const int tp = e / BM, r = e - tp * BM;
+            const int ky = tp / p.kw, kx = tp - ky * p.kw;
+            unsigned oa, ob;
+            src_offsets(s_rn[r], s_ry[r], s_rx[r], ky, kx, oa, ob);
+            s_o1[tp][r] = oa;
+            s_o2[tp][r] = ob;
+        }
+        __syncthreads();
+    }
     auto refresh_offsets = [&]() {
         if (KIND == K_GENERIC || g.mode == MCAV_G_SMALLC) return;
+        if (use_tab) {
+#pragma unroll
+            for (int j = 0; j < T::AROWS; ++j) { o1[j] = s_o1[tap][r0 + T::RPP * j]; o2[j] = s_o2[tap][r0 + T::RPP * j]; }
+            return;
+        }
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
 #pragma unroll
-        for (int j = 0; j < T::AROWS; ++j) {
-            int sy, sx;
-            bool ok = rn[j] >= 0;
-            if (KIND == K_FAST && g.mode == MCAV_G_ADJ_STRIDE2) {
-                const int ty = ry[j] + g.offset - ky, tx = rx[j] + g.offset - kx;      // x[d] collects dy[(d + pad - k) / 2] when whole
-                ok = ok && ty >= 0 && tx >= 0 && (((ty | tx) & 1) == 0);
-                sy = ty >> 1; sx = tx >> 1;
-            } else if (KIND == K_FAST) {
-                sy = ry[j] * g.stride + g.sign * ky + g.offset;
-                sx = rx[j] * g.stride + g.sign * kx + g.offset;
-                if (g.pad_mode == MCAV_PAD_REFLECT) {
-                    sy = reflect_idx(sy, g.Hs);
-                    sx = reflect_idx(sx, g.Ws);
-                }
-            } else {
-                sy = ry[j] + 1 - ky;
-                sx = rx[j] + 1 - kx;
-            }
-            ok = ok && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
-            const int pix = (rn[j] * g.Hs + sy) * g.Ws + sx;
-            const int pix1 = g.up1 ? ((rn[j] * (g.Hs >> 1) + (sy >> 1)) * (g.Ws >> 1) + (sx >> 1)) : pix;
-            o1[j] = ok ? (unsigned)(pix1 * g.C1) * 4u : OOB;
-            o2[j] = ok ? (unsigned)(pix * g.C2) * 4u : OOB;
-        }
+        for (int j = 0; j < T::AROWS; ++j) src_offsets(rn[j], ry[j], rx[j], ky, kx, o1[j], o2[j]);
     };
     refresh_offsets();
 
-    auto load_tile = [&](f32x4 (&ra)[T::AROWS], f32x4 (&rb)[T::BVECS]) {      // global -> registers for the tile at (tap, chunk)
+    unsigned boff[T::BVECS];       // byte offset of this thread's weight columns at kflat = 0 (OOB outside the launch's rows)
+#pragma unroll
+    for (int j = 0; j < T::BVECS; ++j) {
+        const int e = tid + 256 * j, nn = e / T::LPR, cb = e % T::LPR;
+        const bool ok = nn < BN && n0 + nn < p.n_count;
+        boff[j] = ok ? (unsigned)(((p.n_begin + n0 + nn) * p.Kstride + cb * 4) * 4) : OOB;
+    }
+    // `live` = false issues the same loads with out-of-range offsets (they read zero and touch no memory): the K_FAST loop
+    // issues loads unconditionally so that no value merge (and therefore no register copy) sits between an asm load and its wait
+    auto load_tile = [&](f32x4 (&ra)[T::AROWS], f32x4 (&rb)[T::BVECS], bool live) {      // global -> registers for the tile at (tap, chunk)
         int ky, kx, c, kflat;
         if (KIND != K_REFLADJ && g.mode == MCAV_G_SMALLC) {
             const int t4 = chunk * 4 + c4;             // every 16-byte column is its own tap
@@ -259,8 +323,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int j = 0; j < T::AROWS; ++j) {
                 const int sy = ry[j] * g.stride + ky + g.offset, sx = rx[j] * g.stride + kx + g.offset;
-                const bool ok = rn[j] >= 0 && ky >= 0 && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
-                ra[j] = buf_load4(rs1, ok ? (unsigned)(((rn[j] * g.Hs + sy) * g.Ws + sx) * 4) * 4u : OOB);
+                const bool ok = live && rn[j] >= 0 && ky >= 0 && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
+                asm_buf_load4(ra[j], ws1, ok ? (unsigned)(((rn[j] * g.Hs + sy) * g.Ws + sx) * 4) * 4u : OOB);
+            }
+        } else if (KIND == K_FAST) {
+            const bool use2 = chunk * CK >= g.C1;
+            const int cc = use2 ? c - g.C1 : c;
+            const bool cok = live && (use2 ? cc < g.C2 : cc < g.C1);
+            if (use2) {
+#pragma unroll
+                for (int j = 0; j < T::AROWS; ++j) asm_buf_load4(ra[j], ws2, cok ? o2[j] + (unsigned)cc * 4u : OOB);
+            } else {
+#pragma unroll
+                for (int j = 0; j < T::AROWS; ++j) asm_buf_load4(ra[j], ws1, cok ? o1[j] + (unsigned)cc * 4u : OOB);
             }
         } else {
             // the whole 16-channel chunk lies in x1 or in x2 (C1 % 16 == 0 whenever there is an x2): wave-uniform choice
@@ -297,9 +372,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         }
 #pragma unroll
         for (int j = 0; j < T::BVECS; ++j) {
-            const int e = tid + 256 * j, nn = e / T::LPR, cb = e % T::LPR;
-            const bool ok = nn < BN && n0 + nn < p.n_count;
-            rb[j] = buf_load4(rsw, ok ? (unsigned)(((p.n_begin + n0 + nn) * p.Kstride + kflat + cb * 4) * 4) : OOB);
+            const unsigned off = live ? boff[j] + (unsigned)kflat * 4u : OOB;
+            if constexpr (KIND == K_FAST) asm_buf_load4(rb[j], wsw, off);
+            else rb[j] = buf_load4(rsw, off);
         }
     };
     auto store_tile = [&](const f32x4 (&ra)[T::AROWS], const f32x4 (&rb)[T::BVECS], int buf) {
@@ -371,20 +446,49 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     // ---- main loop: tile t is computed from LDS buffer t & 1 while the loads of tiles t + 1 and t + 2 are in flight
     // (two register stages), so a load has a full iteration plus an MFMA phase to land before it is written to LDS.
     f32x4 ra0[T::AROWS], rb0[T::BVECS], ra1[T::AROWS], rb1[T::BVECS];
-    if (T_total > 0) load_tile(ra0, rb0);
-    if (T_total > 1) { advance(); load_tile(ra1, rb1); }
-    if (T_total > 0) store_tile(ra0, rb0, 0);
-    __syncthreads();
-    for (int t = 0; t < T_total; t += 2) {
-        if (t + 2 < T_total) { advance(); load_tile(ra0, rb0); }
-        compute(0);
-        if (t + 1 < T_total) store_tile(ra1, rb1, 1);
+    constexpr int NL = T::AROWS + T::BVECS;       // loads one thread issues per tile
+    if constexpr (KIND == K_FAST) {
+        // hand-counted pipeline: every step issues exactly NL asm loads (dead ones out of range), so "all but the youngest NL"
+        // is always the tile about to be written to LDS
+        const bool mem = !(p.ablate & 1);
+        load_tile(ra0, rb0, mem && T_total > 0);
+        if (T_total > 1) advance();
+        load_tile(ra1, rb1, mem && T_total > 1);
+        vm_wait<NL>();
+        store_tile(ra0, rb0, 0);
         __syncthreads();
-        if (t + 1 >= T_total) break;
-        if (t + 3 < T_total) { advance(); load_tile(ra1, rb1); }
-        compute(1);
-        if (t + 2 < T_total) store_tile(ra0, rb0, 0);
+        for (int t = 0; t < T_total; t += 2) {
+            if (t + 2 < T_total) advance();
+            load_tile(ra0, rb0, mem && t + 2 < T_total);
+            if (!(p.ablate & 2)) compute(0);
+            vm_wait<NL>();
+            store_tile(ra1, rb1, 1);
+            __syncthreads();
+            if (t + 1 >= T_total) break;
+            if (t + 3 < T_total) advance();
+            load_tile(ra1, rb1, mem && t + 3 < T_total);
+            if (!(p.ablate & 2)) compute(1);
+            vm_wait<NL>();
+            store_tile(ra0, rb0, 0);
+            __syncthreads();
+        }
+        vm_wait<0>();                              // nothing may land in a register the epilogue reuses
+    } else {
+        if (T_total > 0) load_tile(ra0, rb0, true);
+        if (T_total > 1) { advance(); load_tile(ra1, rb1, true); }
+        if (T_total > 0) store_tile(ra0, rb0, 0);
         __syncthreads();
+        for (int t = 0; t < T_total; t += 2) {
+            if (t + 2 < T_total) { advance(); load_tile(ra0, rb0, true); }
+            compute(0);
+            if (t + 1 < T_total) store_tile(ra1, rb1, 1);
+            __syncthreads();
+            if (t + 1 >= T_total) break;
+            if (t + 3 < T_total) { advance(); load_tile(ra1, rb1, true); }
+            compute(1);
+            if (t + 2 < T_total) store_tile(ra0, rb0, 0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue.  C/D layout: 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
@@ -798,6 +902,7 @@ inline int pick_tile(const mcav_igemm_desc* d, long M) {
     if (d->n_count <= 32) return 3;
     // measured on MI355X (tools/conv_bench.py): small output tiles with 32-deep K-tiles win at every layer shape of the step --
     // more co-resident workgroups hide the load round trips, and a 32-deep tile halves the barriers per FLOP
+    if (d->mode != MCAV_G_SMALLC && d->Kp % 64 == 0 && ((M + 63) / 64) * ((d->n_count + 63) / 64) < 512) return 11;   // few workgroups: deeper K-tiles
     if (d->mode != MCAV_G_SMALLC && d->Kp % 32 == 0) return 10;
     const long t128x64 = ((M + 127) / 128) * ((d->n_count + 63) / 64);
     return t128x64 >= 1024 ? 1 : 2;
@@ -814,6 +919,7 @@ inline void tile_dims(int id, int& BM, int& BN) {
         case 8: BM = 128; BN = 64; break;
         case 9: BM = 128; BN = 128; break;
         case 10: BM = 64; BN = 64; break;
+        case 11: BM = 64; BN = 64; break;
         default: BM = 64; BN = 16; break;
     }
 }
@@ -840,8 +946,11 @@ inline bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
     const long Mlin = (long)d->B * d->Hd * d->Wd;
     if ((long)d->B * d->Hs * d->Ws * (d->C1 > d->C2 ? d->C1 : d->C2) * 4 >= 0x7fffffffL) return false;   // 32-bit byte offsets
     if ((long)d->Np * kstride_of(d->kh * d->kw, d->Kp) * 4 >= 0x7fffffffL) return false;
-    tile = pick_tile(d, Mlin);
+    p.ablate = (d->tile >> 8) & 3;
+    tile = pick_tile(d, Mlin) & 0xff;
+    if (tile == 0) { mcav_igemm_desc dd = *d; dd.tile = 0; tile = pick_tile(&dd, Mlin); }
     if (tile >= 8 && tile <= 10 && (d->mode == MCAV_G_SMALLC || d->Kp % 32 != 0)) return false;      // 32-deep K-tiles need Kp % 32 == 0
+    if (tile == 11 && (d->mode == MCAV_G_SMALLC || d->Kp % 64 != 0)) return false;
     int BM, BN;
     tile_dims(tile, BM, BN);
     p.groups = d->groups > 1 ? d->groups : 1;
@@ -901,6 +1010,7 @@ MCAV_EXPORT int mcav_igemm(const mcav_igemm_desc* d, void* stream) {
         case 8: launch_igemm<Tile128x64k32>(p, s); break;
         case 9: launch_igemm<Tile128x128k32>(p, s); break;
         case 10: launch_igemm<Tile64x64k32>(p, s); break;
+        case 11: launch_igemm<Tile64x64k64>(p, s); break;
         default: return MCAV_E_INVALID;
     }
     return launch_status();
