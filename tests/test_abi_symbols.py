@@ -39,10 +39,8 @@ def test_python_binding_covers_header():
     import losses  # noqa: F401
     import geometry.pose_geometry  # noqa: F401
     import geometry.transform  # noqa: F401
-    try:
-        import mcav.nn  # noqa: F401
-    except ImportError:
-        pass
+    import mcav.nn  # noqa: F401
+    import mcav.tape  # noqa: F401
     missing = [n for n in declared_symbols() if n not in L._SIGNATURES]
     assert not missing, missing
 

@@ -187,3 +187,33 @@ def test_losses_vs_oracle_at_size(B, H, W):
     grad_close(x.grad, a.grad)
     grad_close(y.grad, b.grad)
     assert rel_err(z.grad, c.grad) < 1e-3
+
+
+def test_multiscale_losses_vs_oracle():
+    """Four disparity scales (DispNetS): every coarser depth is resized bilinearly before warping (losses.py:212-216)."""
+    from losses import Losses
+    from oracle import losses as ol
+    from oracle.step import synthetic_batch
+    B, H, W = 2, 64, 128
+    s = synthetic_batch(B, H, W, seed=31)
+    gen = torch.Generator().manual_seed(32)
+    shapes = [(H, W), (H // 2, W // 2), (H // 4, W // 4), (H // 8, W // 8)]
+    dt = [torch.rand(B, 1, h, w, generator=gen) for h, w in shapes]
+    dr = [torch.rand(B, 1, h, w, generator=gen) for h, w in shapes]
+    poses = 0.01 * torch.randn(B, 2, 6, generator=gen)
+    a = [t.clone().requires_grad_() for t in dt]
+    b = [t.clone().requires_grad_() for t in dr]
+    c = poses.clone().requires_grad_()
+    want = ol.losses_forward(s["tgt"], s["ref_imgs"], [a, b], c, s["intrinsics"])
+    sum(want).backward()
+    x = [t.to(DEV).requires_grad_() for t in dt]
+    y = [t.to(DEV).requires_grad_() for t in dr]
+    z = poses.to(DEV).requires_grad_()
+    got = Losses().forward(s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], [x, y], z, s["intrinsics"].to(DEV), None)
+    assert abs(float(got[0]) - float(want[0])) < 2e-5 * abs(float(want[0]))
+    assert abs(float(got[1]) - float(want[1])) < 2e-5 * abs(float(want[1]))
+    sum(got).backward()
+    for i in range(4):
+        grad_close(x[i].grad, a[i].grad, frac=5e-3, l2=5e-3)
+        grad_close(y[i].grad, b[i].grad, frac=5e-3, l2=5e-3)
+    assert rel_err(z.grad, c.grad) < 5e-3

@@ -11,14 +11,18 @@ DEV = "cuda"
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
-def grads_match(model, g, names, tol):
+def grads_match(model, g, names, tol, l2=False):
     sd = dict(model.named_parameters())
     for n in names:
         gr = sd[n].grad
         assert gr is not None, n
         if gr.numel() > 65536:
             gr = gr[:8, :8]
-        assert rel_err(gr, g["g_" + n.replace(".", "_")]) < tol, n
+        want = torch.from_numpy(g["g_" + n.replace(".", "_")])
+        if l2:      # deep ReLU/BatchNorm stacks: a few activation-mask flips move single entries; compare in the L2 sense
+            assert float((gr.cpu() - want).norm() / want.norm()) < tol, n
+        else:
+            assert rel_err(gr, want) < tol, n
 
 
 def test_posenet_vs_reference(golden):
@@ -65,3 +69,60 @@ def test_dispresnet_vs_reference(golden):
     grads_match(m, g, ["encoder.encoder.conv1.weight", "encoder.encoder.bn1.weight", "encoder.encoder.bn1.bias",
                        "encoder.encoder.layer2.0.downsample.0.weight", "encoder.encoder.layer4.1.bn2.weight",
                        "decoder.decoder.0.conv.conv.bias", "decoder.decoder.10.conv.weight"], 5e-3)
+
+
+def test_dispnets_vs_reference(golden):
+    from models.depth.disp_net import DispNetS
+    g = golden("dispnets.npz")
+    m = reinit_by_name(DispNetS(), 51).to(DEV)
+    m.train()
+    outs = m(T(g["x"]))
+    assert len(outs) == 4
+    for i, o in enumerate(outs):
+        assert rel_err(o, g["disp%d" % (i + 1)]) < 1e-3, i
+    sum((o * T(g["coef%d" % (i + 1)])).sum() for i, o in enumerate(outs)).backward()
+    grads_match(m, g, ["conv1.0.weight", "conv1.2.weight", "upconv7.0.weight", "upconv1.0.bias", "iconv3.0.weight", "predict_disp1.0.weight"], 1e-2, l2=True)
+
+
+def test_posefc_vs_reference(golden):
+    from models.pose.pose_fc import PoseFc
+    g = golden("posefc.npz")
+    m = reinit_by_name(PoseFc(), 61).to(DEV)
+    gen = torch.Generator().manual_seed(62)
+    tgt, r0, r1 = (torch.randn(1, 3, 384, 1280, generator=gen) for _ in range(3))
+    out = m(tgt.to(DEV), [r0.to(DEV), r1.to(DEV)])
+    assert rel_err(out, g["out"]) < 1e-3
+    assert float(out[:, :, :3].abs().max()) == 0.0
+    (out * T(g["coef"])).sum().backward()
+    grads_match(m, g, ["fc_loc.0.weight", "fc_loc.4.weight", "pose_pred.bias", "conv7.0.bias"], 5e-3)
+    with pytest.raises(Exception):
+        m(tgt[:, :, :192, :640].contiguous().to(DEV), [r0[:, :, :192, :640].contiguous().to(DEV), r1[:, :, :192, :640].contiguous().to(DEV)])
+
+
+def test_dispresnet50_vs_oracle():
+    """ResNet-50 encoder (Bottleneck blocks) + decoder with the x4 channel widths (BASELINE.json configs[3]) against the CPU oracle."""
+    from models.depth.resnet_dispnet import DispResNet50
+    from oracle import nets as on
+    hip = reinit_by_name(DispResNet50(), 77)
+    ref = on.DispResNet(50)
+    ref.load_state_dict(hip.state_dict())
+    hip.to(DEV).train()
+    ref.train()
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(2, 3, 64, 128, generator=g)
+    coef = torch.randn(2, 1, 64, 128, generator=g)
+    want = ref(x)[0]
+    (want * coef).sum().backward()
+    got = hip(x.to(DEV))[0]
+    assert rel_err(got, want) < 1e-3
+    (got * coef.to(DEV)).sum().backward()
+    rp = dict(ref.named_parameters())
+    for n, p in hip.named_parameters():
+        if rp[n].grad is None:
+            continue
+        e = float((p.grad.cpu() - rp[n].grad).norm() / rp[n].grad.norm().clamp_min(1e-20))
+        assert e < 2e-2, (n, e)
+    # the stacked two-pass form gives the same disparities
+    hip2 = reinit_by_name(DispResNet50(), 77).to(DEV).train()
+    a, b = hip2.forward_pair(x.to(DEV), x.flip(0).contiguous().to(DEV))
+    assert rel_err(a[0], want) < 1e-3

@@ -70,6 +70,44 @@ def block_backward(blk, sv, dout, addend=None):
     return N.conv_dgrad(c1, dr1, hw(x), addend=dxd)
 
 
+# ------------------------------------------------------------------------------------------------ Bottleneck (ResNet-50/101/152)
+def bottleneck_forward(blk, x, stride, train, groups=1):
+    """torchvision Bottleneck (v1.5: the stride sits on the 3x3): 1x1 -> 3x3(stride) -> 1x1(x4), BN after each, residual, ReLU."""
+    sv = {"x": x, "stride": stride}
+    sv["r1"], sv["st1"], sv["h1"] = conv_bn(blk.conv1, blk.bn1, x, 1, 0, train, True, groups=groups)
+    sv["r2"], sv["st2"], sv["h2"] = conv_bn(blk.conv2, blk.bn2, sv["h1"], stride, 1, train, True, groups=groups)
+    if blk.downsample is not None:
+        sv["rd"], sv["std"], idt = conv_bn(blk.downsample[0], blk.downsample[1], x, stride, 0, train, False, groups=groups)
+    else:
+        idt = x
+    sv["r3"], sv["st3"], sv["out"] = conv_bn(blk.conv3, blk.bn3, sv["h2"], 1, 0, train, True, residual=idt, groups=groups)
+    return sv["out"], sv
+
+
+def bottleneck_backward(blk, sv, dout, addend=None):
+    x, stride = sv["x"], sv["stride"]
+    c1 = spec_of(blk.conv1, 1, 0, N.PAD_ZERO)
+    c2 = spec_of(blk.conv2, stride, 1, N.PAD_ZERO)
+    c3 = spec_of(blk.conv3, 1, 0, N.PAD_ZERO)
+    dr3, dz = N.bn_backward(blk.bn3, sv["st3"], dout, sv["out"], sv["r3"], True, want_dres=True)
+    N.conv_wgrad(c3, sv["h2"], dr3)
+    dh2 = N.conv_dgrad(c3, dr3, hw(sv["h2"]))
+    dr2 = N.bn_backward(blk.bn2, sv["st2"], dh2, sv["h2"], sv["r2"], True)
+    N.conv_wgrad(c2, sv["h1"], dr2)
+    dh1 = N.conv_dgrad(c2, dr2, hw(sv["h1"]))
+    dr1 = N.bn_backward(blk.bn1, sv["st1"], dh1, sv["h1"], sv["r1"], True)
+    N.conv_wgrad(c1, x, dr1)
+    if blk.downsample is None:
+        if addend is not None:
+            dz = N.add(dz, addend)
+        return N.conv_dgrad(c1, dr1, hw(x), addend=dz)
+    cd = spec_of(blk.downsample[0], stride, 0, N.PAD_ZERO)
+    drd = N.bn_backward(blk.downsample[1], sv["std"], dz, None, sv["rd"], False)
+    N.conv_wgrad(cd, x, drd)
+    dxd = N.conv_dgrad(cd, drd, hw(x), addend=addend)
+    return N.conv_dgrad(c1, dr1, hw(x), addend=dxd)
+
+
 # ------------------------------------------------------------------------------------------------ encoder
 STAGES = ("layer1", "layer2", "layer3", "layer4")
 
@@ -84,7 +122,8 @@ def encoder_forward(net, x4, train, groups=1):
     for si, name in enumerate(STAGES):
         stage_sv = []
         for bi, blk in enumerate(getattr(net, name)):
-            x, bsv = block_forward(blk, x, 2 if (si > 0 and bi == 0) else 1, train, groups)
+            fwd = bottleneck_forward if hasattr(blk, "conv3") else block_forward
+            x, bsv = fwd(blk, x, 2 if (si > 0 and bi == 0) else 1, train, groups)
             stage_sv.append(bsv)
         blocks.append(stage_sv)
         feats.append(x)
@@ -100,7 +139,8 @@ def encoder_backward(net, sv, dfeats):
         blks = list(getattr(net, STAGES[si]))
         for bi in range(len(blks) - 1, -1, -1):
             addend = dfeats[si] if (bi == 0 and si > 0) else None      # skip-connection gradient of this stage's input
-            dcur = block_backward(blks[bi], sv["blocks"][si][bi], dcur, addend)
+            bwd = bottleneck_backward if hasattr(blks[bi], "conv3") else block_backward
+            dcur = bwd(blks[bi], sv["blocks"][si][bi], dcur, addend)
     # dcur = gradient w.r.t. the max-pool output; f0 also feeds the decoder
     df0 = N.maxpool_bwd(dcur, sv["idx"], tuple(feats[0].shape), dx=dfeats[0], accumulate=True)
     dc1 = N.bn_backward(net.bn1, sv["st"], df0, feats[0], sv["c1"], True)

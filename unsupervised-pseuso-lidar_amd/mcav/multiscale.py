@@ -54,5 +54,43 @@ def smooth_loss(pred_map):
     return _SmoothFn.apply(*[m.contiguous() for m in pred_map])
 
 
+class _ResizeFn(torch.autograd.Function):
+    """F.interpolate(D, [H, W], mode='bilinear', align_corners=False) on [B,1,h,w] maps (losses.py:214-215)."""
+
+    @staticmethod
+    def forward(ctx, D, H, W):
+        D = L.dev(D.contiguous(), "depth")
+        B, C, h, w = D.shape
+        out = torch.empty((B, 1, H, W), dtype=torch.float32, device=D.device)
+        L.check(L.lib().mcav_resize_bilinear_fwd(L.ptr(D), B, h, w, L.ptr(out), H, W, 0.0, 0.0, L.stream()), "mcav_resize_bilinear_fwd")
+        ctx.dims = (B, h, w, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, h, w, H, W = ctx.dims
+        g = L.dev(g.contiguous(), "grad")
+        out = torch.empty((B, 1, h, w), dtype=torch.float32, device=g.device)
+        L.check(L.lib().mcav_resize_bilinear_bwd(L.ptr(g), B, h, w, L.ptr(out), H, W, 0.0, 0.0, 0, L.stream()), "mcav_resize_bilinear_bwd")
+        return out, None, None
+
+
 def multiscale_losses(tgt, refs, disparity, poses, K, inputs_are_depth=False):
-    raise L.MCAVError("multi-scale depth lists are not wired yet (single-scale DispResNet path only)")
+    """Losses.forward for depth nets that return several scales (DispNetS).  Per scale: depth (from disparity), bilinear resize
+    to the image size, the fused 3-warp L1 kernel on the resized depths; smoothness on the native-resolution depths of tgt."""
+    import losses as LS                      # the fused kernel's autograd node
+    from geometry.pose_geometry import disp_to_depth
+    from mcav import tape  # noqa: F401  (registers the resize entry points)
+    depths = disparity if inputs_are_depth else disp_to_depth(disparity)
+    n = len(depths[0])
+    H, W = tgt.shape[-2:]
+    tw = (0.5 / (2 * n), 0.5 / (2 * n), 1.0 / (2 * n))      # mean of the two tgt-view terms; every term / (2 n)  (losses.py:227-240)
+    total = None
+    for s in range(n):
+        Dt, Dr = depths[0][s], depths[1][s]
+        if Dt.shape[-1] != W:
+            Dt, Dr = _ResizeFn.apply(Dt, H, W), _ResizeFn.apply(Dr, H, W)
+        l0, _ = LS._WarpLossFn.apply(Dt.contiguous(), Dr.contiguous(), poses.contiguous(), tgt.contiguous(), refs[0].contiguous(),
+                                     refs[1].contiguous(), K.contiguous(), L.WL_INPUT_DEPTH | L.WL_NO_SMOOTH, tw)
+        total = l0 if total is None else total + l0
+    return [total, smooth_loss(depths[0])]

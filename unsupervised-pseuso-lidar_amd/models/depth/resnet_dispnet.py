@@ -16,7 +16,7 @@ from mcav import depthnet as E
 from mcav.holders import BNParams, ConvParams, LinearParams
 from .layers import ConvBlock, Conv3x3
 
-BLOCK_COUNTS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
+BLOCK_COUNTS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
 
 
 class BasicBlock(nn.Module):
@@ -32,13 +32,29 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
 
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = ConvParams(inplanes, planes, 1, bias=False)
+        self.bn1 = BNParams(planes)
+        self.conv2 = ConvParams(planes, planes, 3, bias=False)      # carries the stride (torchvision's v1.5 layout)
+        self.bn2 = BNParams(planes)
+        self.conv3 = ConvParams(planes, planes * 4, 1, bias=False)
+        self.bn3 = BNParams(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+
 class ResNet(nn.Module):
-    """torchvision.models.resnet{18,34} parameter layout (conv1, bn1, layer1-4, fc)."""
+    """torchvision.models.resnet{18,34,50,101,152} parameter layout (conv1, bn1, layer1-4, fc)."""
 
     def __init__(self, num_layers=18):
         super().__init__()
         if num_layers not in BLOCK_COUNTS:
-            raise ValueError("ResNet-%s is not built yet (BasicBlock nets 18/34 only)" % num_layers)
+            raise ValueError("{} is not a valid number of resnet layers".format(num_layers))
+        block = BasicBlock if num_layers <= 34 else Bottleneck
         self.conv1 = ConvParams(3, 64, 7, bias=False)
         self.bn1 = BNParams(64)
         inplanes = 64
@@ -47,12 +63,12 @@ class ResNet(nn.Module):
             for bi in range(n):
                 stride = 2 if (si > 0 and bi == 0) else 1
                 ds = None
-                if stride != 1 or inplanes != planes:
-                    ds = nn.Sequential(ConvParams(inplanes, planes, 1, bias=False), BNParams(planes))
-                blocks.append(BasicBlock(inplanes, planes, stride, ds))
-                inplanes = planes
+                if stride != 1 or inplanes != planes * block.expansion:
+                    ds = nn.Sequential(ConvParams(inplanes, planes * block.expansion, 1, bias=False), BNParams(planes * block.expansion))
+                blocks.append(block(inplanes, planes, stride, ds))
+                inplanes = planes * block.expansion
             setattr(self, "layer%d" % (si + 1), nn.Sequential(*blocks))
-        self.fc = LinearParams(512, 1000)          # unused by the depth net; kept for state_dict compatibility
+        self.fc = LinearParams(512 * block.expansion, 1000)          # unused by the depth net; kept for state_dict compatibility
         for m in self.modules():
             if isinstance(m, ConvParams):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -84,6 +100,8 @@ class ResnetEncoder(nn.Module):
         super().__init__()
         self.num_ch_enc = np.array([64, 64, 128, 256, 512])
         self.encoder = ResNet(num_layers)
+        if num_layers > 34:
+            self.num_ch_enc[1:] *= 4
 
     def forward(self, x):
         """img [B,3,H,W] -> 5 feature maps (NCHW), differentiable w.r.t. the parameters."""
@@ -198,9 +216,10 @@ class _DispResNetPairFn(torch.autograd.Function):
 
 
 class DispResNet(nn.Module):
-    def __init__(self):
+    def __init__(self, num_layers=18):
+        """The reference hard-codes ResNet-18 (resnet_dispnet.py:101); num_layers=50 is BASELINE.json's configs[3] extension."""
         super().__init__()
-        self.encoder = ResnetEncoder(18, True)
+        self.encoder = ResnetEncoder(num_layers, True)
         self.decoder = DepthDecoder(self.encoder.num_ch_enc)
 
     def forward(self, x):
@@ -210,3 +229,10 @@ class DispResNet(nn.Module):
         """== (self(xa), self(xb)) evaluated in that order, as one stacked launch set (see _DispResNetPairFn)."""
         da, db = _DispResNetPairFn.apply(xa, xb, self, *self.parameters())
         return [da], [db]
+
+
+class DispResNet50(DispResNet):
+    """No-argument ResNet-50 variant so a config file can name it (model.depth.name: DispResNet50)."""
+
+    def __init__(self):
+        super().__init__(50)
