@@ -66,8 +66,15 @@ def make_step(depth, pose, opt, crit, samples, pair=True, graph=False):
 
     runner = fwd_bwd
     if graph:
-        from mcav.graph import GraphedForwardBackward
-        runner = GraphedForwardBackward(fwd_bwd, opt.arena(), [tgt, refs[0], refs[1], K])
+        try:
+            from mcav.graph import GraphedForwardBackward
+            runner = GraphedForwardBackward(fwd_bwd, opt.arena(), [tgt, refs[0], refs[1], K])
+        except Exception as e:       # a failed capture must not cost the measurement: same launches, issued eagerly
+            print("bench.py: hipGraph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
+            torch.cuda.synchronize()
+            runner = fwd_bwd
+    if graph:
+        make_step.graphed = runner is not fwd_bwd
 
     def step():
         loss = runner(tgt, refs[0], refs[1], K)
@@ -109,7 +116,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--separate-passes", action="store_true", help="run the two depth passes as separate launch sets (default: stacked)")
-    ap.add_argument("--graph", action="store_true", help="replay forward+backward as one captured hipGraph")
+    ap.add_argument("--no-graph", dest="graph", action="store_false",
+                    help="issue every launch eagerly (default: forward+backward replayed as one captured hipGraph, eager fallback if capture fails)")
+    ap.set_defaults(graph=True)
     ap.add_argument("--layer-report", default=None, help="write a per-launch table of the instrumented step to this file")
     args = ap.parse_args()
 
@@ -156,7 +165,7 @@ def main():
                                   "fp32, one step = 2x depth fwd + pose fwd + warp/L1/smooth loss + backward + Adam%s" %
                                   (B, H, W, " + 1 RCCL all-reduce of the 63.7 MB gradient arena" if world > 1 else ""),
                       "global_batch": B * world, "parallelism": "dp%d" % world},
-           "loss": [round(float(l), 6) for l in loss]}
+           "loss": [round(float(l.detach()), 6) for l in loss], "hipgraph": bool(getattr(make_step, "graphed", False))}
 
     if rank == 0 and not args.no_roofline:
         # instrumented step(s): every conv launch bracketed by events on the launch stream

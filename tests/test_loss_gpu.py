@@ -184,9 +184,11 @@ def test_losses_vs_oracle_at_size(B, H, W):
     assert abs(float(got[0]) - float(want[0])) < 1e-5 * abs(float(want[0]))
     assert abs(float(got[1]) - float(want[1])) < 1e-5 * abs(float(want[1]))
     sum(got).backward()
-    grad_close(x.grad, a.grad)
-    grad_close(y.grad, b.grad)
-    assert rel_err(z.grad, c.grad) < 1e-3
+    # d loss / d disp = -10 D^2 * d loss / d D with D up to 100: a few near pixels carry most of the gradient norm, so one L1 sign
+    # flip among them moves the L2 error to the 1e-2 level; the element-wise mismatch fraction is the tight check here
+    grad_close(x.grad, a.grad, l2=3e-2)
+    grad_close(y.grad, b.grad, l2=3e-2)
+    assert rel_err(z.grad, c.grad) < 5e-3      # a sum over 4.4 M sign terms: measured 1e-3..2.6e-3 depending on the host's CPU kernels
 
 
 def test_multiscale_losses_vs_oracle():
@@ -217,3 +219,22 @@ def test_multiscale_losses_vs_oracle():
         grad_close(x[i].grad, a[i].grad, frac=5e-3, l2=5e-3)
         grad_close(y[i].grad, b[i].grad, frac=5e-3, l2=5e-3)
     assert rel_err(z.grad, c.grad) < 5e-3
+
+
+def test_loss_kernel_is_bit_reproducible():
+    """Fixed-order reductions (no float atomics): two launches on the same inputs give identical bits."""
+    from losses import Losses
+    from oracle.step import synthetic_batch
+    B, H, W = 4, 96, 160
+    s = synthetic_batch(B, H, W, seed=41)
+    gen = torch.Generator().manual_seed(42)
+    dt, dr = torch.rand(B, 1, H, W, generator=gen).to(DEV), torch.rand(B, 1, H, W, generator=gen).to(DEV)
+    poses = (0.01 * torch.randn(B, 2, 6, generator=gen)).to(DEV)
+    outs = []
+    for _ in range(2):
+        x, y, z = dt.clone().requires_grad_(), dr.clone().requires_grad_(), poses.clone().requires_grad_()
+        l = Losses().forward(s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], [[x], [y]], z, s["intrinsics"].to(DEV), None)
+        sum(l).backward()
+        outs.append((l[0].detach().clone(), l[1].detach().clone(), x.grad.clone(), y.grad.clone(), z.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -61,7 +61,8 @@ struct IgemmParams {
     int M;           // rows of the GEMM (incl. class / group padding)
     int Mc, McP;     // ADJ_STRIDE2: pixels per parity class and its BM-padded size; groups > 1: rows per group and padded size
     int groups;
-    int ablate;      // diagnostics only (tile | 0x100: issue every load out of range; tile | 0x200: skip the MFMAs)
+    int ablate;      // diagnostics only, via desc.tile bits 8..12: 1 loads out of range, 2 skip MFMAs+LDS reads, 4 LDS reads only once,
+                     // 8 skip LDS writes, 16 skip the per-tile barrier (results are garbage with 4/8/16; timing experiments only)
     int mtiles, ntiles;
 };
 
@@ -214,16 +215,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
         return (((cls_py + g.offset - ky) | (cls_px + g.offset - kx)) & 1) == 0;
     };
-    int T_total;
-    if (KIND != K_REFLADJ && g.mode == MCAV_G_SMALLC) {
-        T_total = (p.taps * 4 + CK - 1) / CK;
-    } else {
+    // valid taps of this workgroup, listed once (the K loop just walks the list)
+    __shared__ int s_tl[64];
+    __shared__ int s_nt;
+    if (tid == 0) {
         int nv = 0;
-        for (int t = 0; t < p.taps; ++t) nv += tap_ok(t) ? 1 : 0;
-        T_total = nv * nchunks;
+        for (int t = 0; t < p.taps && t < 64; ++t)
+            if (tap_ok(t)) s_tl[nv++] = t;
+        s_nt = nv;
     }
-    int tap = 0, chunk = 0;
-    if (!(KIND != K_REFLADJ && g.mode == MCAV_G_SMALLC)) while (tap < p.taps && !tap_ok(tap)) ++tap;
+    __syncthreads();
+    const bool smallc = KIND != K_REFLADJ && g.mode == MCAV_G_SMALLC;
+    const int T_total = smallc ? (p.taps * 4 + CK - 1) / CK : s_nt * nchunks;
+    int ti = 0, chunk = 0;
+    int tap = smallc ? 0 : __builtin_amdgcn_readfirstlane(s_tl[0]);
 
     // ---- cached per-row source BYTE offsets of the current tap (K_FAST / K_REFLADJ); OOB = reads as zero
     unsigned o1[T::AROWS], o2[T::AROWS];
@@ -239,9 +244,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1, bytes1);
     const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(g.C2 > 0 ? g.x2 : g.x1, g.C2 > 0 ? bytes2 : 0u);
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, (unsigned)((size_t)(p.n_begin + p.n_count) * p.Kstride * 4));
-    const u32x4 ws1 = make_rsrc_words(g.x1, bytes1);
-    const u32x4 ws2 = make_rsrc_words(g.C2 > 0 ? g.x2 : g.x1, g.C2 > 0 ? bytes2 : 0u);
-    const u32x4 wsw = make_rsrc_words(p.w, (unsigned)((size_t)(p.n_begin + p.n_count) * p.Kstride * 4));
     // source byte offsets (x1, x2) of destination pixel (n, dy, dx) under tap (ky, kx); OOB when the tap falls outside
     auto src_offsets = [&](int n, int dy, int dx, int ky, int kx, unsigned& oa, unsigned& ob) {
         int sy, sx;
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             for (int j = 0; j < T::AROWS; ++j) {
                 const int sy = ry[j] * g.stride + ky + g.offset, sx = rx[j] * g.stride + kx + g.offset;
                 const bool ok = live && rn[j] >= 0 && ky >= 0 && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
-                asm_buf_load4(ra[j], ws1, ok ? (unsigned)(((rn[j] * g.Hs + sy) * g.Ws + sx) * 4) * 4u : OOB);
+                ra[j] = buf_load4(rs1, ok ? (unsigned)(((rn[j] * g.Hs + sy) * g.Ws + sx) * 4) * 4u : OOB);
             }
         } else if (KIND == K_FAST) {
             const bool use2 = chunk * CK >= g.C1;
@@ -332,10 +334,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             const bool cok = live && (use2 ? cc < g.C2 : cc < g.C1);
             if (use2) {
 #pragma unroll
-                for (int j = 0; j < T::AROWS; ++j) asm_buf_load4(ra[j], ws2, cok ? o2[j] + (unsigned)cc * 4u : OOB);
+                for (int j = 0; j < T::AROWS; ++j) ra[j] = buf_load4(rs2, cok ? o2[j] + (unsigned)cc * 4u : OOB);
             } else {
 #pragma unroll
-                for (int j = 0; j < T::AROWS; ++j) asm_buf_load4(ra[j], ws1, cok ? o1[j] + (unsigned)cc * 4u : OOB);
+                for (int j = 0; j < T::AROWS; ++j) ra[j] = buf_load4(rs1, cok ? o1[j] + (unsigned)cc * 4u : OOB);
             }
         } else {
             // the whole 16-channel chunk lies in x1 or in x2 (C1 % 16 == 0 whenever there is an x2): wave-uniform choice
@@ -373,8 +375,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < T::BVECS; ++j) {
             const unsigned off = live ? boff[j] + (unsigned)kflat * 4u : OOB;
-            if constexpr (KIND == K_FAST) asm_buf_load4(rb[j], wsw, off);
-            else rb[j] = buf_load4(rsw, off);
+            rb[j] = buf_load4(rsw, off);
         }
     };
     auto store_tile = [&](const f32x4 (&ra)[T::AROWS], const f32x4 (&rb)[T::BVECS], int buf) {
@@ -386,12 +387,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
             if (nn < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nn][cb * 4]) = rb[j];
         }
     };
-    auto advance = [&]() {
-        if (KIND != K_REFLADJ && g.mode == MCAV_G_SMALLC) { ++chunk; return; }
+    auto advance = [&]() {       // only called while another tile exists
+        if (smallc) { ++chunk; return; }
         if (++chunk == nchunks) {
             chunk = 0;
-            do { ++tap; } while (tap < p.taps && !tap_ok(tap));
-            if (tap < p.taps) refresh_offsets();
+            tap = __builtin_amdgcn_readfirstlane(s_tl[++ti]);
+            refresh_offsets();
         }
     };
 
@@ -445,52 +446,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
     // ---- main loop: tile t is computed from LDS buffer t & 1 while the loads of tiles t + 1 and t + 2 are in flight
     // (two register stages), so a load has a full iteration plus an MFMA phase to land before it is written to LDS.
-    f32x4 ra0[T::AROWS], rb0[T::BVECS], ra1[T::AROWS], rb1[T::BVECS];
-    constexpr int NL = T::AROWS + T::BVECS;       // loads one thread issues per tile
-    if constexpr (KIND == K_FAST) {
-        // hand-counted pipeline: every step issues exactly NL asm loads (dead ones out of range), so "all but the youngest NL"
-        // is always the tile about to be written to LDS
-        const bool mem = !(p.ablate & 1);
-        load_tile(ra0, rb0, mem && T_total > 0);
-        if (T_total > 1) advance();
-        load_tile(ra1, rb1, mem && T_total > 1);
-        vm_wait<NL>();
-        store_tile(ra0, rb0, 0);
-        __syncthreads();
-        for (int t = 0; t < T_total; t += 2) {
-            if (t + 2 < T_total) advance();
-            load_tile(ra0, rb0, mem && t + 2 < T_total);
-            if (!(p.ablate & 2)) compute(0);
-            vm_wait<NL>();
-            store_tile(ra1, rb1, 1);
-            __syncthreads();
-            if (t + 1 >= T_total) break;
-            if (t + 3 < T_total) advance();
-            load_tile(ra1, rb1, mem && t + 3 < T_total);
-            if (!(p.ablate & 2)) compute(1);
-            vm_wait<NL>();
-            store_tile(ra0, rb0, 0);
-            __syncthreads();
-        }
-        vm_wait<0>();                              // nothing may land in a register the epilogue reuses
-    } else {
-        if (T_total > 0) load_tile(ra0, rb0, true);
-        if (T_total > 1) { advance(); load_tile(ra1, rb1, true); }
-        if (T_total > 0) store_tile(ra0, rb0, 0);
-        __syncthreads();
-        for (int t = 0; t < T_total; t += 2) {
-            if (t + 2 < T_total) { advance(); load_tile(ra0, rb0, true); }
-            compute(0);
-            if (t + 1 < T_total) store_tile(ra1, rb1, 1);
-            __syncthreads();
-            if (t + 1 >= T_total) break;
-            if (t + 3 < T_total) { advance(); load_tile(ra1, rb1, true); }
-            compute(1);
-            if (t + 2 < T_total) store_tile(ra0, rb0, 0);
-            __syncthreads();
-        }
+    // ---- main loop ("write early"): iteration t
+    //   1. the loads of tile t+1 (issued one iteration ago) have landed: write them to LDS buffer (t+1)&1
+    //   2. issue the loads of tile t+2 into the same registers
+    //   3. MFMAs of tile t from buffer t&1 -- they cover the LDS-write latency of (1) and the flight of (2)
+    //   4. one barrier
+    // One register stage, exact s_waitcnt (everything outstanding at (1) is tile t+1), no LDS-write latency on the critical path.
+    f32x4 ra[T::AROWS], rb[T::BVECS];
+    const bool mem = !(p.ablate & 1);
+    if (T_total > 0) {
+        load_tile(ra, rb, mem);
+        store_tile(ra, rb, 0);
+        if (T_total > 1) { advance(); load_tile(ra, rb, mem); }
     }
-
+    __syncthreads();
+    for (int t = 0; t < T_total; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T_total) {
+            if (!(p.ablate & 8)) store_tile(ra, rb, buf ^ 1);
+            if (t + 2 < T_total) { advance(); load_tile(ra, rb, mem); }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the loads ABOVE the MFMAs (the scheduler otherwise sinks them below the barrier)
+        if (!(p.ablate & 2)) compute((p.ablate & 4) ? 0 : buf);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.ablate & 16)) __syncthreads();
+    }
     // ---- epilogue.  C/D layout: 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
     //                           16x16: col = lane & 15, row = 4 (lane >> 4) + r.   Registers 4q..4q+3 are 4 consecutive rows.
     constexpr int MF = T::MF;
@@ -928,7 +908,7 @@ inline bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
     if (!d || !d->x1 || !d->w || !d->y) return false;
     if (d->B <= 0 || d->Hs <= 0 || d->Ws <= 0 || d->Hd <= 0 || d->Wd <= 0 || d->C1 <= 0 || d->C2 < 0) return false;
     if (d->C2 > 0 && !d->x2) return false;
-    if (d->kh <= 0 || d->kw <= 0 || d->Np <= 0 || d->Kp <= 0) return false;
+    if (d->kh <= 0 || d->kw <= 0 || d->Np <= 0 || d->Kp <= 0 || d->kh * d->kw > 64) return false;
     if (d->n_begin < 0 || d->n_count <= 0 || d->n_begin + d->n_count > d->Np) return false;
     if (d->mode == MCAV_G_SMALLC) { if (d->Kp != 4 || d->C1 != 4 || d->C2 != 0) return false; }
     else if (d->Kp % CK != 0 || d->Kp < d->C1 + d->C2) return false;
@@ -946,7 +926,7 @@ inline bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
     const long Mlin = (long)d->B * d->Hd * d->Wd;
     if ((long)d->B * d->Hs * d->Ws * (d->C1 > d->C2 ? d->C1 : d->C2) * 4 >= 0x7fffffffL) return false;   // 32-bit byte offsets
     if ((long)d->Np * kstride_of(d->kh * d->kw, d->Kp) * 4 >= 0x7fffffffL) return false;
-    p.ablate = (d->tile >> 8) & 3;
+    p.ablate = (d->tile >> 8) & 31;
     tile = pick_tile(d, Mlin) & 0xff;
     if (tile == 0) { mcav_igemm_desc dd = *d; dd.tile = 0; tile = pick_tile(&dd, Mlin); }
     if (tile >= 8 && tile <= 10 && (d->mode == MCAV_G_SMALLC || d->Kp % 32 != 0)) return false;      // 32-deep K-tiles need Kp % 32 == 0
