@@ -30,6 +30,18 @@ import torch  # noqa: E402
 # conv FLOPs fwd per triplet at 192x640 R18 = 2 x 16.03 + 0.89 GF; fwd + dgrad + wgrad = 3x
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+TRAFFIC_JSON = os.path.join(REPO, "profiles", "r01_traffic.json")      # rocprofv3 PMC passes (tools/pmc_summary.py)
+
+
+def measured_traffic(steps_in_profile=3):
+    """HBM bytes from the committed PMC passes of this same workload: (conv stage per step, fused loss kernel per launch)."""
+    try:
+        k = json.load(open(TRAFFIC_JSON))["kernels"]
+    except Exception:
+        return None, None
+    conv = sum(v["hbm_bytes_per_launch"] * v["launches"] for n, v in k.items() if "igemm_kernel" in n or "wgrad_kernel" in n)
+    warp = [v["hbm_bytes_per_launch"] for n, v in k.items() if "warp_loss_kernel" in n]
+    return conv / steps_in_profile, (warp[0] if warp else None)
 
 
 def synthetic_samples(B, H, W, rank, step=0):
@@ -193,8 +205,11 @@ def main():
             a[1] += e0.elapsed_time(e1) / 3.0
             a[2] += 1
         ach = flops / (ms * 1e-3) / 1e12
+        conv_traffic, warp_traffic = measured_traffic() if (B, H, W) == (12, 192, 640) else (None, None)
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": conv_traffic,
+                           "traffic_note": "HBM bytes of the conv stage per step, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the rocprofv3 --pmc passes "
+                                           "in profiles/r01_traffic.json (null when absent)",
                            "kernel": "conv stage = igemm_kernel (fwd+dgrad) + wgrad_kernel, all launches of one step",
                            "launches_per_step": len(recs) // 3, "algorithmic_gflop_per_step": round(flops / 1e9, 2),
                            "kernel_ms_per_step": round(ms, 3),
@@ -204,7 +219,7 @@ def main():
             lms = sum(e0.elapsed_time(e1) for (_, e0, e1) in lrecs) / len(lrecs)
             lbytes = 52.0 * B * H * W
             out["roofline_warp"] = {"bound": "hbm", "achieved": round(lbytes / (lms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                    "frac": round(lbytes / (lms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                                    "frac": round(lbytes / (lms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": warp_traffic,
                                     "kernel": "warp_loss_kernel (+prepare/finalize), 52 B/pixel x %d pixels" % (B * H * W), "ms": round(lms, 4)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B, H, W)

@@ -96,6 +96,12 @@ int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t workspace_bytes
 int mcav_pack_weights(const float* w_oihw, int Cout, int Cin, int kh, int kw, int transposed, float* packed, int Np, int Kp,
                       void* stream);
 
+/* The same for many filters in ONE launch.  items_dev: device array of nitems records
+ *   { const float* src; float* dst; int Cout, Cin, taps, transposed, Np, Kp, Kstride, first_block; }   (48 bytes each)
+ * where Kstride = taps * Kp rounded up to 16 and first_block is the running sum of ceil(Np * Kstride / 1024) over the
+ * preceding records; nblocks = that sum over all records. */
+int mcav_pack_weights_multi(const void* items_dev, int nitems, int nblocks, void* stream);
+
 /* NCHW image [B, C, H, W] -> NHWC [B, H, W, Cp] at channel offset choff (other channels untouched; zero the buffer first). */
 int mcav_nchw_to_nhwc(const float* src, int B, int C, int H, int W, float* dst, int Cp, int choff, void* stream);
 int mcav_nhwc_to_nchw(const float* src, int B, int C, int H, int W, int Cp, int choff, float* dst, void* stream);

@@ -872,6 +872,38 @@ __global__ void pack_weights_kernel(const float* w, int Cout, int Cin, int taps,
     }
 }
 
+// Many filters in one launch: after an optimiser step every packed copy is stale; one launch re-derives them all.
+struct PackItem {
+    const float* src;
+    float* dst;
+    int Cout, Cin, taps, transposed, Np, Kp, Kstride, first_block;   // first_block: prefix sum of 256-thread blocks (4 elements per thread)
+};
+
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem* items, int nitems) {
+    // binary search the item that owns this block
+    int lo = 0, hi = nitems - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackItem it = items[lo];
+    const size_t total = (size_t)it.Np * it.Kstride;
+    const size_t base = ((size_t)(blockIdx.x - it.first_block) * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const size_t e = base + u;
+        if (e >= total) return;
+        const int n = (int)(e / it.Kstride), kf = (int)(e - (size_t)n * it.Kstride);
+        const int tap = kf / it.Kp, k = kf - tap * it.Kp;
+        float v = 0.f;
+        if (tap < it.taps) {
+            const int co = it.transposed ? k : n, ci = it.transposed ? n : k;
+            if (co < it.Cout && ci < it.Cin) v = it.src[((size_t)co * it.Cin + ci) * it.taps + tap];
+        }
+        it.dst[e] = v;
+    }
+}
+
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
 inline int kstride_of(int taps, int Kp) { return round_up(taps * Kp, CK); }
@@ -1117,5 +1149,12 @@ MCAV_EXPORT int mcav_pack_weights(const float* w_oihw, int Cout, int Cin, int kh
     const size_t total = (size_t)Np * Kstride;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     pack_weights_kernel<<<blocks, 256, 0, as_stream(stream)>>>(w_oihw, Cout, Cin, taps, transposed, packed, Np, Kp, Kstride);
+    return launch_status();
+}
+
+// items: device array of PackItem-compatible records {src, dst, Cout, Cin, taps, transposed, Np, Kp, Kstride, first_block}
+MCAV_EXPORT int mcav_pack_weights_multi(const void* items_dev, int nitems, int nblocks, void* stream) {
+    if (!items_dev || nitems <= 0 || nblocks <= 0) return MCAV_E_INVALID;
+    pack_weights_multi_kernel<<<nblocks, 256, 0, as_stream(stream)>>>(reinterpret_cast<const PackItem*>(items_dev), nitems);
     return launch_status();
 }

@@ -40,6 +40,7 @@ L.register({
     "mcav_wgrad_workspace_bytes": (c_sz, [ctypes.POINTER(WgradDesc)]),
     "mcav_wgrad": (c_i, [ctypes.POINTER(WgradDesc), c_p, c_sz, c_p]),
     "mcav_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "mcav_pack_weights_multi": (c_i, [c_p, c_i, c_i, c_p]),
     "mcav_nchw_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "mcav_nhwc_to_nchw": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "mcav_bn_finalize": (c_i, [c_p, c_i, c_i, c_d, c_p, c_p, c_f, c_f] + [c_p] * 6 + [c_i, c_p]),
@@ -98,6 +99,62 @@ def P(t):
 
 
 # ------------------------------------------------------------------------------------------------ conv parameters
+class _PackItem(ctypes.Structure):
+    _fields_ = [("src", c_p), ("dst", c_p), ("Cout", c_i), ("Cin", c_i), ("taps", c_i), ("transposed", c_i), ("Np", c_i), ("Kp", c_i),
+                ("Kstride", c_i), ("first_block", c_i)]
+
+
+class PackRegistry:
+    """Every packed filter copy that has been requested so far.  After an optimiser step all of them are stale; the first one
+    that is asked for re-derives ALL of them with one mcav_pack_weights_multi launch (instead of ~80 small ones)."""
+
+    def __init__(self):
+        self.entries = []          # (spec, transposed)
+        self.table = None
+        self.nblocks = 0
+        self.signature = None
+
+    def add(self, spec, transposed):
+        import weakref
+        self.entries.append((weakref.ref(spec), transposed))
+        self.table = None
+
+    def _build(self, device, live):
+        items = (_PackItem * len(live))()
+        blk = 0
+        for it, (spec, tr) in zip(items, live):
+            buf = spec._bwd if tr else spec._fwd
+            np_, kp_ = (up16(spec.cin), up16(spec.cout)) if tr else (spec.np, spec.kp)
+            it.src, it.dst = spec.weight.data_ptr(), buf.data_ptr()
+            it.Cout, it.Cin, it.taps, it.transposed = spec.cout, spec.cin, spec.kh * spec.kw, int(tr)
+            it.Np, it.Kp, it.Kstride, it.first_block = np_, kp_, buf.shape[1], blk
+            blk += (np_ * buf.shape[1] + 1023) // 1024
+        raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+        self.table = raw.to(device)
+        self.nblocks = blk
+
+
+    def repack_all(self, device):
+        self.entries = [(r, tr) for r, tr in self.entries if r() is not None]          # drop specs of deleted modules
+        live = [(r(), tr) for r, tr in self.entries]
+        live = [(s, tr) for s, tr in live if s is not None and s.weight.device == device and (s._bwd if tr else s._fwd) is not None]
+        if not live:
+            return
+        sig = tuple((s.weight.data_ptr(), (s._bwd if tr else s._fwd).data_ptr()) for s, tr in live)
+        if self.table is None or sig != self.signature or self.table.device != device:
+            self._build(device, live)
+            self.signature = sig
+        L.check(L.lib().mcav_pack_weights_multi(P(self.table), len(live), self.nblocks, L.stream()), "mcav_pack_weights_multi")
+        for s, tr in live:
+            if tr:
+                s._key_b = s._key()
+            else:
+                s._key_f = s._key()
+
+
+PACKS = PackRegistry()
+
+
 class ConvSpec:
     """Static description of one convolution + the packed copies of its weight (kept fresh lazily)."""
 
@@ -122,9 +179,12 @@ class ConvSpec:
             kstride = up16(taps * self.kp)
             if self._fwd is None or self._fwd.device != self.weight.device:
                 self._fwd = empty((self.np, kstride), self.weight)
-            L.check(L.lib().mcav_pack_weights(P(self.weight), self.cout, self.cin, self.kh, self.kw, 0, P(self._fwd), self.np, self.kp,
-                                              L.stream()), "mcav_pack_weights")
-            self._key_f = key
+                L.check(L.lib().mcav_pack_weights(P(self.weight), self.cout, self.cin, self.kh, self.kw, 0, P(self._fwd), self.np, self.kp,
+                                                  L.stream()), "mcav_pack_weights")
+                self._key_f = key
+                PACKS.add(self, False)
+            else:
+                PACKS.repack_all(self.weight.device)       # one launch refreshes every registered copy (this one included)
         return self._fwd
 
     def packed_bwd(self):
@@ -135,9 +195,12 @@ class ConvSpec:
             npd, kpd = up16(self.cin), up16(self.cout)
             if self._bwd is None or self._bwd.device != self.weight.device:
                 self._bwd = empty((npd, taps * kpd), self.weight)
-            L.check(L.lib().mcav_pack_weights(P(self.weight), self.cout, self.cin, self.kh, self.kw, 1, P(self._bwd), npd, kpd, L.stream()),
-                    "mcav_pack_weights")
-            self._key_b = key
+                L.check(L.lib().mcav_pack_weights(P(self.weight), self.cout, self.cin, self.kh, self.kw, 1, P(self._bwd), npd, kpd, L.stream()),
+                        "mcav_pack_weights")
+                self._key_b = key
+                PACKS.add(self, True)
+            else:
+                PACKS.repack_all(self.weight.device)
         return self._bwd
 
 
