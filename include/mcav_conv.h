@@ -112,7 +112,9 @@ int mcav_nhwc_to_nchw(const float* src, int B, int C, int H, int W, int Cp, int 
  *   running_mean / running_var (unbiased) with `momentum`.  count = pixels per channel. */
 int mcav_bn_finalize(const float* stats, int mtiles, int C, double count, const float* gamma, const float* beta, float eps,
                      float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* save_mean,
-                     float* save_invstd, int groups, void* stream);
+                     float* save_invstd, int groups, void* workspace, size_t workspace_bytes, void* stream);
+/* Layers with many tiles are reduced in two stages (fp64 partials in `workspace`); 0 bytes = the workspace may be NULL. */
+size_t mcav_bn_finalize_workspace_bytes(int mtiles, int C, int groups);
 /* groups > 1: `stats` holds groups * mtiles rows, `count` is per group, scale/shift/save_* are [groups][C], and the running
  * statistics are updated once per group, in group order (exactly as `groups` consecutive forward passes would). */
 /* eval mode: scale/shift from the running statistics */

@@ -61,9 +61,8 @@ struct IgemmParams {
     int M;           // rows of the GEMM (incl. class / group padding)
     int Mc, McP;     // ADJ_STRIDE2: pixels per parity class and its BM-padded size; groups > 1: rows per group and padded size
     int groups;
-    int ablate;      // diagnostics only, via desc.tile bits 8..12: 1 loads out of range, 2 skip MFMAs+LDS reads, 4 LDS reads only once,
-                     // 8 skip LDS writes, 16 skip the per-tile barrier (results are garbage with 4/8/16; timing experiments only)
     int mtiles, ntiles;
+    int no_tab;      // desc.tile bit 8: force the general kernel (A/B timing and parity of both paths)
 };
 
 // destination pixel of GEMM row m: returns false for padding rows.
@@ -163,6 +162,87 @@ __device__ __forceinline__ void vm_wait() {
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
+// Epilogue shared by the forward/dgrad kernels: bias, activation, optional act'(aux) factor and addend, 2x2 sum-pool, channel-range
+// store, BatchNorm column sums.  C/D layout: 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
+//                                            16x16: col = lane & 15, row = 4 (lane >> 4) + r.   Registers 4q..4q+3 are 4 consecutive rows.
+template <class T>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, typename T::AccT (&acc)[T::TM][T::TN], const int* s_out,
+                                               float (*s_stat)[2][T::BN], int tid, int wm0, int wn0, int n0, int mt) {
+    constexpr int BN = T::BN;
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int MF = T::MF;
+    const int ccol = lane & (MF - 1);
+    float ssum[T::TN], ssq[T::TN];
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) {
+            const int nl = n0 + wn0 + j * MF + ccol;          // column within this launch
+            const bool ncol = nl < p.n_count;
+            const float bv = (p.bias && ncol) ? p.bias[p.n_begin + nl] : 0.f;
+#pragma unroll
+            for (int q = 0; q < T::ACC / 4; ++q) {
+                const int rbase = wm0 + i * MF + (MF == 32 ? 8 * q + 4 * (lane >> 5) : 4 * (lane >> 4));
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fwd(acc[i][j][4 * q + e] + bv, p.act);
+                if (p.pool) {
+                    const int o = s_out[rbase];
+                    if (o >= 0 && ncol) {
+                        float s = (v[0] + v[1]) + (v[2] + v[3]);
+                        const size_t off = (size_t)o * p.Cd + p.y_choff + nl;
+                        if (p.dact_aux) s *= act_bwd(p.dact_aux[off], p.dact);
+                        if (p.addend) s += p.addend[off];
+                        p.y[off] = s;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int o = s_out[rbase + e];
+                        if (o >= 0 && ncol) {
+                            float s = v[e];
+                            const size_t off = (size_t)o * p.Cd + p.y_choff + nl;
+                            if (p.dact_aux) s *= act_bwd(p.dact_aux[off], p.dact);
+                            if (p.addend) s += p.addend[off];
+                            p.y[off] = s;
+                            ssum[j] += s;
+                            ssq[j] += s * s;
+                        }
+                    }
+                }
+            }
+        }
+    if (p.stats) {
+        // column sums over this workgroup's rows: lanes holding the same column, then the wavefronts stacked along M
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) {
+            if (MF == 32) {
+                ssum[j] += __shfl_xor(ssum[j], 32, 64);
+                ssq[j] += __shfl_xor(ssq[j], 32, 64);
+            } else {
+                ssum[j] += __shfl_xor(ssum[j], 16, 64); ssq[j] += __shfl_xor(ssq[j], 16, 64);
+                ssum[j] += __shfl_xor(ssum[j], 32, 64); ssq[j] += __shfl_xor(ssq[j], 32, 64);
+            }
+            if (lane < MF) {
+                s_stat[wave / T::WAVES_N][0][wn0 + j * MF + lane] = ssum[j];
+                s_stat[wave / T::WAVES_N][1][wn0 + j * MF + lane] = ssq[j];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * BN; e += 256) {
+            const int which = e / BN, col = e - which * BN;
+            if (n0 + col < p.n_count) {
+                float s = 0.f;
+#pragma unroll
+                for (int wmi = 0; wmi < T::WAVES_M; ++wmi) s += s_stat[wmi][which][col];
+                p.stats[((size_t)mt * 2 + which) * p.n_count + n0 + col] = s;
+            }
+        }
+    }
 }
 
 template <class T, int KIND>
@@ -453,97 +533,239 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     //   4. one barrier
     // One register stage, exact s_waitcnt (everything outstanding at (1) is tile t+1), no LDS-write latency on the critical path.
     f32x4 ra[T::AROWS], rb[T::BVECS];
-    const bool mem = !(p.ablate & 1);
     if (T_total > 0) {
-        load_tile(ra, rb, mem);
+        load_tile(ra, rb, true);
         store_tile(ra, rb, 0);
-        if (T_total > 1) { advance(); load_tile(ra, rb, mem); }
+        if (T_total > 1) { advance(); load_tile(ra, rb, true); }
     }
     __syncthreads();
     for (int t = 0; t < T_total; ++t) {
         const int buf = t & 1;
         if (t + 1 < T_total) {
-            if (!(p.ablate & 8)) store_tile(ra, rb, buf ^ 1);
-            if (t + 2 < T_total) { advance(); load_tile(ra, rb, mem); }
+            store_tile(ra, rb, buf ^ 1);
+            if (t + 2 < T_total) { advance(); load_tile(ra, rb, true); }
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the loads ABOVE the MFMAs (the scheduler otherwise sinks them below the barrier)
-        if (!(p.ablate & 2)) compute((p.ablate & 4) ? 0 : buf);
+        compute(buf);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(p.ablate & 16)) __syncthreads();
+        __syncthreads();
     }
-    // ---- epilogue.  C/D layout: 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
-    //                           16x16: col = lane & 15, row = 4 (lane >> 4) + r.   Registers 4q..4q+3 are 4 consecutive rows.
-    constexpr int MF = T::MF;
-    const int ccol = lane & (MF - 1);
-    float ssum[T::TN], ssq[T::TN];
+    igemm_epilogue<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
+}
+
+// ------------------------------------------------------------------------------------------------ table-driven kernel
+// The kernel the step spends its time in (every 1x1 / 3x3 layer whose channel counts are whole K-tiles: DIRECT gathers with
+// zero / reflection padding, stride 1 / 2, fused upsample + concat, and the stride-2 adjoint).  Same tiling, LDS layout and
+// epilogue as igemm_kernel, but NOTHING besides loads, LDS traffic and MFMAs is left inside the K loop:
+//   * all source addressing is done once per workgroup into per-(tap, row) byte-offset tables in LDS (out-of-image taps
+//     and padding rows hold an out-of-range offset, which a raw buffer load returns as zero);
+//   * a K-tile's loads are `buffer_load_dwordx4 v, v_off, s[rsrc], s_chunk offen`: the per-row offset register changes
+//     only when the tap changes, the channel-chunk offset is the instruction's SCALAR offset -- zero VALU per load;
+//   * the loop is unrolled by two so that every LDS address is a base register plus an immediate;
+//   * the accumulators never leave their registers (no conditional around the MFMAs).
+// fp32 MFMA and the VALU share the SIMD's FMA datapath on gfx950 (equal peak rates): an address instruction in the loop costs
+// MFMA time, and the previous loop spent about a third of its issue slots on them.
+__device__ __forceinline__ f32x4 buf_load4s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int sbyte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, sbyte_off, 0));
+}
+
+constexpr int TAB_TAPS = 9;
+
+template <class T>
+__global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
+    constexpr int BM = T::BM, BN = T::BN, CKT = T::KD;
+    __shared__ __attribute__((aligned(16))) float As[2][BM][T::LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][T::LD];
+    __shared__ int s_out[BM];
+    __shared__ float s_stat[T::WAVES_M][2][BN];
+    __shared__ unsigned s_o1[TAB_TAPS][BM], s_o2[TAB_TAPS][BM];
+    __shared__ int s_rn[BM], s_ry[BM], s_rx[BM];
+    __shared__ int s_tl[TAB_TAPS + 1];
+    __shared__ int s_nt;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = lid % p.ntiles, mt = lid / p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const GatherSrc& g = p.g;
+
+    // ---- once per workgroup: destination pixel of every tile row, the tap list, the offset tables
+    for (int r = tid; r < BM; r += 256) {
+        int n, dy, dx;
+        const bool ok = decode_row(p, m0 + r, n, dy, dx);
+        int o = -1;
+        if (ok) o = p.pool ? ((n * (p.Hd >> 1) + (dy >> 1)) * (p.Wd >> 1) + (dx >> 1)) : ((n * p.Hd + dy) * p.Wd + dx);
+        s_out[r] = o;
+        s_rn[r] = ok ? n : -1; s_ry[r] = dy; s_rx[r] = dx;
+    }
+    if (tid == 0) {      // ADJ_STRIDE2 tiles hold one parity class of destination pixels and visit only that class's taps
+        int nv = 0;
+        const bool adj = g.mode == MCAV_G_ADJ_STRIDE2;
+        const int cls = adj ? m0 / p.McP : 0, cpy = cls >> 1, cpx = cls & 1;
+        for (int t = 0; t < p.taps; ++t) {
+            const int ky = t / p.kw, kx = t - ky * p.kw;
+            if (!adj || (((cpy + g.offset - ky) | (cpx + g.offset - kx)) & 1) == 0) s_tl[nv++] = t;
+        }
+        s_tl[nv] = 0;
+        s_nt = nv;
+    }
+    __syncthreads();
+    for (int e = tid; e < p.taps * BM; e += 256) {
+        const int tp = e / BM, r = e - tp * BM;
+        const int ky = tp / p.kw, kx = tp - ky * p.kw;
+        const int n = s_rn[r], dy = s_ry[r], dx = s_rx[r];
+        int sy, sx;
+        bool ok = n >= 0;
+        if (g.mode == MCAV_G_ADJ_STRIDE2) {
+            const int ty = dy + g.offset - ky, tx = dx + g.offset - kx;      // x[d] collects dy[(d + pad - k) / 2] when whole
+            ok = ok && ty >= 0 && tx >= 0 && (((ty | tx) & 1) == 0);
+            sy = ty >> 1; sx = tx >> 1;
+        } else {
+            sy = dy * g.stride + g.sign * ky + g.offset;
+            sx = dx * g.stride + g.sign * kx + g.offset;
+            if (g.pad_mode == MCAV_PAD_REFLECT) {
+                sy = reflect_idx(sy, g.Hs);
+                sx = reflect_idx(sx, g.Ws);
+            }
+        }
+        ok = ok && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
+        const int pix = (n * g.Hs + sy) * g.Ws + sx;
+        const int pix1 = g.up1 ? ((n * (g.Hs >> 1) + (sy >> 1)) * (g.Ws >> 1) + (sx >> 1)) : pix;
+        s_o1[tp][r] = ok ? (unsigned)(pix1 * g.C1) * 4u : OOB;
+        s_o2[tp][r] = ok ? (unsigned)(pix * g.C2) * 4u : OOB;
+    }
+    __syncthreads();
+
+    const int ntaps = s_nt;
+    const int nchunks = p.Kp / CKT;
+    const int T_total = ntaps * nchunks;
+    const unsigned bytes1 = (unsigned)((size_t)g.B * (g.up1 ? (g.Hs >> 1) * (g.Ws >> 1) : g.Hs * g.Ws) * g.C1 * 4);
+    const unsigned bytes2 = (unsigned)((size_t)g.B * g.Hs * g.Ws * g.C2 * 4);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1, bytes1);
+    const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(g.C2 > 0 ? g.x2 : g.x1, g.C2 > 0 ? bytes2 : 0u);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, (unsigned)((size_t)(p.n_begin + p.n_count) * p.Kstride * 4));
+
+    // ---- this thread's share of a K-tile: AROWS rows of A (16-byte column c4), BVECS 16-byte pieces of B
+    const int c4 = tid % T::LPR, r0 = tid / T::LPR;
+    unsigned boff[T::BVECS];
 #pragma unroll
-    for (int j = 0; j < T::TN; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+    for (int j = 0; j < T::BVECS; ++j) {
+        const int e = tid + 256 * j, nn = e / T::LPR, cb = e % T::LPR;
+        const bool ok = nn < BN && n0 + nn < p.n_count;
+        boff[j] = ok ? (unsigned)(((p.n_begin + n0 + nn) * p.Kstride + cb * 4) * 4) : OOB;
+    }
+    int ti = 0, chunk = 0;                       // the ISSUE pointer: next K-tile to load
+    int tap = __builtin_amdgcn_readfirstlane(s_tl[0]);
+    unsigned oa[T::AROWS], ob[T::AROWS];
+    auto refresh = [&]() {
+#pragma unroll
+        for (int j = 0; j < T::AROWS; ++j) {
+            oa[j] = s_o1[tap][r0 + T::RPP * j] + (unsigned)c4 * 16u;      // OOB + 16 c4 is still out of range
+            ob[j] = s_o2[tap][r0 + T::RPP * j] + (unsigned)c4 * 16u;
+        }
+    };
+    refresh();
+    auto issue = [&](f32x4 (&ra)[T::AROWS], f32x4 (&rb)[T::BVECS]) {
+        const int cbase = chunk * CKT;
+        if (cbase < g.C1) {
+#pragma unroll
+            for (int j = 0; j < T::AROWS; ++j) ra[j] = buf_load4s(rs1, oa[j], cbase * 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < T::AROWS; ++j) ra[j] = buf_load4s(rs2, ob[j], (cbase - g.C1) * 4);
+        }
+        const int kb = (tap * p.Kp + cbase) * 4;
+#pragma unroll
+        for (int j = 0; j < T::BVECS; ++j) rb[j] = buf_load4s(rsw, boff[j], kb);
+        if (++chunk == nchunks) {
+            chunk = 0;
+            ++ti;
+            tap = __builtin_amdgcn_readfirstlane(s_tl[ti]);      // s_tl[ntaps] = 0: harmless after the last tile
+            refresh();
+        }
+    };
+    constexpr bool BFULL = (BN * T::LPR) % 256 == 0;             // every thread owns a B piece: no predicated LDS write in the loop
+    auto store = [&](const f32x4 (&ra)[T::AROWS], const f32x4 (&rb)[T::BVECS], auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+        for (int j = 0; j < T::AROWS; ++j) *reinterpret_cast<f32x4*>(&As[buf][r0 + T::RPP * j][c4 * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < T::BVECS; ++j) {
+            const int e = tid + 256 * j, nn = e / T::LPR, cb = e % T::LPR;
+            if (BFULL || nn < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nn][cb * 4]) = rb[j];
+        }
+    };
+
+    const int wm0 = (wave / T::WAVES_N) * T::WM, wn0 = (wave % T::WAVES_N) * T::WN;
+    typename T::AccT acc[T::TM][T::TN];
 #pragma unroll
     for (int i = 0; i < T::TM; ++i)
 #pragma unroll
-        for (int j = 0; j < T::TN; ++j) {
-            const int nl = n0 + wn0 + j * MF + ccol;          // column within this launch
-            const bool ncol = nl < p.n_count;
-            const float bv = (p.bias && ncol) ? p.bias[p.n_begin + nl] : 0.f;
+        for (int j = 0; j < T::TN; ++j)
 #pragma unroll
-            for (int q = 0; q < T::ACC / 4; ++q) {
-                const int rbase = wm0 + i * MF + (MF == 32 ? 8 * q + 4 * (lane >> 5) : 4 * (lane >> 4));
-                float v[4];
+            for (int r = 0; r < T::ACC; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int MFR = T::MF;                                     // fragment rows: 32 (32x32x2) or 16 (16x16x4)
+    constexpr int KSUB = MFR == 32 ? 8 : 16;                       // K depth covered by one ds_read_b128 per lane (4 MFMAs)
+    const int frow = lane & (MFR - 1), fk = (lane / MFR) * 4;
+    auto compute = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_fwd(acc[i][j][4 * q + e] + bv, p.act);
-                if (p.pool) {
-                    const int o = s_out[rbase];
-                    if (o >= 0 && ncol) {
-                        float s = (v[0] + v[1]) + (v[2] + v[3]);
-                        const size_t off = (size_t)o * p.Cd + p.y_choff + nl;
-                        if (p.dact_aux) s *= act_bwd(p.dact_aux[off], p.dact);
-                        if (p.addend) s += p.addend[off];
-                        p.y[off] = s;
+        for (int ks = 0; ks < CKT / KSUB; ++ks) {
+            f32x4 a[T::TM], b[T::TN];
+#pragma unroll
+            for (int i = 0; i < T::TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][wm0 + i * MFR + frow][ks * KSUB + fk]);
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][wn0 + j * MFR + frow][ks * KSUB + fk]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::TN; ++j) {
+                        if constexpr (MFR == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
                     }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int o = s_out[rbase + e];
-                        if (o >= 0 && ncol) {
-                            float s = v[e];
-                            const size_t off = (size_t)o * p.Cd + p.y_choff + nl;
-                            if (p.dact_aux) s *= act_bwd(p.dact_aux[off], p.dact);
-                            if (p.addend) s += p.addend[off];
-                            p.y[off] = s;
-                            ssum[j] += s;
-                            ssq[j] += s * s;
-                        }
-                    }
-                }
-            }
         }
-    if (p.stats) {
-        // column sums over this workgroup's rows: lanes holding the same column, then the wavefronts stacked along M
-#pragma unroll
-        for (int j = 0; j < T::TN; ++j) {
-            if (MF == 32) {
-                ssum[j] += __shfl_xor(ssum[j], 32, 64);
-                ssq[j] += __shfl_xor(ssq[j], 32, 64);
-            } else {
-                ssum[j] += __shfl_xor(ssum[j], 16, 64); ssq[j] += __shfl_xor(ssq[j], 16, 64);
-                ssum[j] += __shfl_xor(ssum[j], 32, 64); ssq[j] += __shfl_xor(ssq[j], 32, 64);
-            }
-            if (lane < MF) {
-                s_stat[wave / T::WAVES_N][0][wn0 + j * MF + lane] = ssum[j];
-                s_stat[wave / T::WAVES_N][1][wn0 + j * MF + lane] = ssq[j];
-            }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+
+    // ---- main loop ("write early").  Invariant at the top of step t: LDS buffer t & 1 holds tile t, the registers hold the
+    // in-flight loads of tile t + 1, the issue pointer is at tile t + 2.  A step writes tile t + 1 to the other buffer (the only
+    // loads outstanding are exactly that tile's), issues tile t + 2 into the same registers, runs the MFMAs of tile t -- which
+    // cover the LDS-write latency and the flight of the new loads -- and ends with the one barrier.
+    f32x4 ra[T::AROWS], rb[T::BVECS];
+    auto step = [&](auto cur, auto nxt) {
+        store(ra, rb, nxt);
+        issue(ra, rb);
+        __builtin_amdgcn_sched_barrier(0);      // keep the loads above the MFMAs
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    };
+    int t = 0;
+    if (T_total > 0) {
+        issue(ra, rb);
+        store(ra, rb, B0{});
+        if (T_total > 1) issue(ra, rb);
+    }
+    __syncthreads();
+    for (; t + 3 < T_total; t += 2) {
+        step(B0{}, B1{});
+        step(B1{}, B0{});
+    }
+    for (; t < T_total; ++t) {                   // the last one to three tiles
+        if (t & 1) {
+            if (t + 1 < T_total) { store(ra, rb, B0{}); if (t + 2 < T_total) issue(ra, rb); }
+            compute(B1{});
+        } else {
+            if (t + 1 < T_total) { store(ra, rb, B1{}); if (t + 2 < T_total) issue(ra, rb); }
+            compute(B0{});
         }
         __syncthreads();
-        for (int e = tid; e < 2 * BN; e += 256) {
-            const int which = e / BN, col = e - which * BN;
-            if (n0 + col < p.n_count) {
-                float s = 0.f;
-#pragma unroll
-                for (int wmi = 0; wmi < T::WAVES_M; ++wmi) s += s_stat[wmi][which][col];
-                p.stats[((size_t)mt * 2 + which) * p.n_count + n0 + col] = s;
-            }
-        }
     }
+    igemm_epilogue<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -958,7 +1180,7 @@ inline bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
     const long Mlin = (long)d->B * d->Hd * d->Wd;
     if ((long)d->B * d->Hs * d->Ws * (d->C1 > d->C2 ? d->C1 : d->C2) * 4 >= 0x7fffffffL) return false;   // 32-bit byte offsets
     if ((long)d->Np * kstride_of(d->kh * d->kw, d->Kp) * 4 >= 0x7fffffffL) return false;
-    p.ablate = (d->tile >> 8) & 31;
+    p.no_tab = (d->tile >> 8) & 1;
     tile = pick_tile(d, Mlin) & 0xff;
     if (tile == 0) { mcav_igemm_desc dd = *d; dd.tile = 0; tile = pick_tile(&dd, Mlin); }
     if (tile >= 8 && tile <= 10 && (d->mode == MCAV_G_SMALLC || d->Kp % 32 != 0)) return false;      // 32-deep K-tiles need Kp % 32 == 0
@@ -990,7 +1212,10 @@ inline void launch_igemm(const IgemmParams& p, hipStream_t s) {
     const bool c4ok = (p.g.C1 & 3) == 0 && (p.g.C2 & 3) == 0 && (p.g.C2 == 0 || (p.g.C1 & 15) == 0);
     const int grid = p.mtiles * p.ntiles;
     const bool fast_mode = p.g.mode == MCAV_G_DIRECT || (p.g.mode == MCAV_G_ADJ_STRIDE2 && p.g.C2 == 0) || p.g.mode == MCAV_G_SMALLC;
-    if (fast_mode && c4ok) igemm_kernel<T, K_FAST><<<grid, 256, 0, s>>>(p);
+    const bool tab = (p.g.mode == MCAV_G_DIRECT || (p.g.mode == MCAV_G_ADJ_STRIDE2 && p.g.C2 == 0)) && c4ok && p.taps <= TAB_TAPS &&
+                     p.g.C1 + p.g.C2 == p.Kp && p.Kp % T::KD == 0 && (p.g.C2 == 0 || p.g.C1 % T::KD == 0) && !p.no_tab;
+    if (tab) igemm_tab_kernel<T><<<grid, 256, 0, s>>>(p);
+    else if (fast_mode && c4ok) igemm_kernel<T, K_FAST><<<grid, 256, 0, s>>>(p);
     else if (p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0) igemm_kernel<T, K_REFLADJ><<<grid, 256, 0, s>>>(p);
     else igemm_kernel<T, K_GENERIC><<<grid, 256, 0, s>>>(p);
 }

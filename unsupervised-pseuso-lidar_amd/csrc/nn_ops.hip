@@ -29,14 +29,42 @@ __global__ void nhwc_to_nchw_kernel(const float* src, int B, int C, int H, int W
 }
 
 // ---------------------------------------------------------------------------------------------- BatchNorm
-// stats: [mtiles][2][C] per-tile sums of x and x^2 (from the conv epilogue).  32 channels x 8 tile-slices per block.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, int mtiles, int C, double count, const float* gamma, const float* beta,
+// stats: [groups][mtiles][2][C] per-tile sums of x and x^2 (from the conv epilogue).
+// Stage 1 (only when there are many tiles): grid (C/64, slices, groups); a block sums one slice of the tiles for 64 channels
+// with 4 tile lanes, in fp64, into part[group][slice][2][C].  Stage 2: 32 channels x 8 slice lanes per block, fixed order.
+constexpr int BNF_SLICES = 128;        // upper bound of stage-1 slices
+constexpr int BNF_DIRECT = 64;         // up to this many tiles the finalize kernel reads the fp32 slabs itself
+
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* stats, int mtiles, int C, int per_slice, double* part) {
+    __shared__ double s1[4][64], s2[4][64];
+    const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const int slice = blockIdx.y, g = blockIdx.z, nsl = gridDim.y;
+    const float* st = stats + (size_t)g * mtiles * 2 * C;
+    const int t0 = slice * per_slice, t1 = min(mtiles, t0 + per_slice);
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int t = t0 + tl; t < t1; t += 4) {
+            a += (double)st[((size_t)t * 2 + 0) * C + c];
+            b += (double)st[((size_t)t * 2 + 1) * C + c];
+        }
+    s1[tl][cl] = a; s2[tl][cl] = b;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+        for (int k = 1; k < 4; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        double* o = part + ((size_t)g * nsl + slice) * 2 * C;
+        o[c] = a;
+        o[C + c] = b;
+    }
+}
+
+template <class TIn>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const TIn* stats, int mtiles, int C, double count, const float* gamma, const float* beta,
                                                           float eps, float momentum, float* running_mean, float* running_var, float* scale,
                                                           float* shift, float* save_mean, float* save_invstd, int groups) {
     __shared__ double s1[8][32], s2[8][32];
     const int cl = threadIdx.x & 31, part = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     for (int g = 0; g < groups; ++g) {          // groups are finalised in order: running statistics see pass 0, then pass 1, ...
-        const float* st = stats + (size_t)g * mtiles * 2 * C;
+        const TIn* st = stats + (size_t)g * mtiles * 2 * C;
         double a = 0.0, b = 0.0;
         if (c < C)
             for (int t = part; t < mtiles; t += 8) {
@@ -318,14 +346,32 @@ MCAV_EXPORT int mcav_nhwc_to_nchw(const float* src, int B, int C, int H, int W, 
     return launch_status();
 }
 
+MCAV_EXPORT size_t mcav_bn_finalize_workspace_bytes(int mtiles, int C, int groups) {
+    if (groups < 1) groups = 1;
+    if (mtiles <= BNF_DIRECT || C <= 0) return 0;
+    return align_up(sizeof(double) * 2 * (size_t)C * BNF_SLICES * groups, 256);
+}
+
 MCAV_EXPORT int mcav_bn_finalize(const float* stats, int mtiles, int C, double count, const float* gamma, const float* beta, float eps, float momentum,
                                  float* running_mean, float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
-                                 int groups, void* stream) {
+                                 int groups, void* workspace, size_t workspace_bytes, void* stream) {
     if (groups < 1) groups = 1;
     if (!stats || !gamma || !beta || !scale || !shift || !save_mean || !save_invstd || mtiles <= 0 || C <= 0 || count <= 0) return MCAV_E_INVALID;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MCAV_E_INVALID;
-    bn_finalize_kernel<<<(C + 31) / 32, 256, 0, as_stream(stream)>>>(stats, mtiles, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale,
-                                                                      shift, save_mean, save_invstd, groups);
+    hipStream_t s = as_stream(stream);
+    if (mtiles <= BNF_DIRECT) {
+        bn_finalize_kernel<float><<<(C + 31) / 32, 256, 0, s>>>(stats, mtiles, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale,
+                                                                shift, save_mean, save_invstd, groups);
+        return launch_status();
+    }
+    if (!workspace || workspace_bytes < mcav_bn_finalize_workspace_bytes(mtiles, C, groups)) return MCAV_E_WORKSPACE;
+    int per_slice = (mtiles + BNF_SLICES - 1) / BNF_SLICES;
+    if (per_slice < 8) per_slice = 8;
+    const int slices = (mtiles + per_slice - 1) / per_slice;
+    double* part = reinterpret_cast<double*>(workspace);
+    bn_partial_kernel<<<dim3((C + 63) / 64, slices, groups), 256, 0, s>>>(stats, mtiles, C, per_slice, part);
+    bn_finalize_kernel<double><<<(C + 31) / 32, 256, 0, s>>>(part, slices, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale,
+                                                             shift, save_mean, save_invstd, groups);
     return launch_status();
 }
 

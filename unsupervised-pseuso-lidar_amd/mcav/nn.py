@@ -43,7 +43,8 @@ L.register({
     "mcav_pack_weights_multi": (c_i, [c_p, c_i, c_i, c_p]),
     "mcav_nchw_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "mcav_nhwc_to_nchw": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
-    "mcav_bn_finalize": (c_i, [c_p, c_i, c_i, c_d, c_p, c_p, c_f, c_f] + [c_p] * 6 + [c_i, c_p]),
+    "mcav_bn_finalize": (c_i, [c_p, c_i, c_i, c_d, c_p, c_p, c_f, c_f] + [c_p] * 6 + [c_i, c_p, c_sz, c_p]),
+    "mcav_bn_finalize_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "mcav_bn_eval_coeffs": (c_i, [c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p]),
     "mcav_bn_apply": (c_i, [c_p, c_p, c_p, c_p, c_i, c_sz, c_i, c_p, c_sz, c_p]),
     "mcav_bn_bwd_workspace_bytes": (c_sz, [c_sz, c_i, c_i]),
@@ -325,9 +326,13 @@ def bn_train_coeffs(bn, slab, count, groups=1):
     buf = empty((4, groups, C), bn.weight)
     st.scale, st.shift, st.mean, st.invstd = buf[0], buf[1], buf[2], buf[3]
     st.groups = groups
-    L.check(L.lib().mcav_bn_finalize(P(slab), slab.shape[0] // groups, C, float(count), P(bn.weight), P(bn.bias), bn.eps, bn.momentum,
-                                     P(bn.running_mean), P(bn.running_var), P(st.scale), P(st.shift), P(st.mean), P(st.invstd), groups,
-                                     L.stream()), "mcav_bn_finalize")
+    h = L.lib()
+    mtiles = slab.shape[0] // groups
+    nbytes = h.mcav_bn_finalize_workspace_bytes(mtiles, C, groups)
+    ws = L.workspace(nbytes, slab.device, "bn_fin") if nbytes else None
+    L.check(h.mcav_bn_finalize(P(slab), mtiles, C, float(count), P(bn.weight), P(bn.bias), bn.eps, bn.momentum,
+                               P(bn.running_mean), P(bn.running_var), P(st.scale), P(st.shift), P(st.mean), P(st.invstd), groups,
+                               P(ws), ws.numel() if ws is not None else 0, L.stream()), "mcav_bn_finalize")
     bn.num_batches_tracked += groups
     return st
 
