@@ -102,6 +102,19 @@ int mcav_pack_weights(const float* w_oihw, int Cout, int Cin, int kh, int kw, in
  * preceding records; nblocks = that sum over all records. */
 int mcav_pack_weights_multi(const void* items_dev, int nitems, int nblocks, void* stream);
 
+/* 3x3 reflection-padded convolution with ONE output channel -- the decoder's disparity heads (reference
+ * models/depth/resnet_dispnet.py:66-68 `dispconv`, layers.py:42-58 Conv3x3, applied with a sigmoid at :93-94).  HBM-bound
+ * stencil kernels instead of an N = 1 implicit GEMM.  x NHWC [B,H,W,C], C in {16, 32, 64, 128}; w_oihw [1][C][3][3].
+ *   fwd: y[B,H,W] = act(conv(x) + bias[0]).
+ *   bwd: with dpre = dy * act'(y):  dx = adjoint(dpre) * x_act'(x) + addend   (x_act = the activation that PRODUCED x, its
+ *        derivative taken through x; addend may be NULL),  dw_oihw (+)= wgrad,  dbias[0] (+)= sum(dpre)  -- one pass over x. */
+int mcav_conv3x3r_c1_fwd(const float* x, int B, int H, int W, int C, const float* w_oihw, const float* bias, int act, float* y,
+                         void* stream);
+size_t mcav_conv3x3r_c1_bwd_workspace_bytes(int C);
+int mcav_conv3x3r_c1_bwd(const float* x, int B, int H, int W, int C, const float* w_oihw, const float* dy, const float* y, int act,
+                         int x_act, const float* addend, float* dx, float* dw_oihw, float* dbias, int accumulate, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* NCHW image [B, C, H, W] -> NHWC [B, H, W, Cp] at channel offset choff (other channels untouched; zero the buffer first). */
 int mcav_nchw_to_nhwc(const float* src, int B, int C, int H, int W, float* dst, int Cp, int choff, void* stream);
 int mcav_nhwc_to_nchw(const float* src, int B, int C, int H, int W, int Cp, int choff, float* dst, void* stream);

@@ -216,3 +216,33 @@ def test_maxpool_adam_misc():
     t = torch.randn(3, 2, 5, 12, generator=g)
     out = N.spatial_mean(t.to(DEV), 0.06)
     assert rel_err(out, 0.06 * t.mean((1, 2))) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 12, 16), (1, 2, 2, 16), (2, 3, 5, 32), (1, 37, 70, 16), (1, 6, 9, 64), (1, 4, 4, 128)])
+def test_one_channel_head_stencil(shape):
+    """The disparity head (3x3 reflect conv to ONE channel + sigmoid): stencil forward and the fused one-pass backward
+    (d input through ELU' + addend, weight and bias gradients) against torch, including the reflected border lines."""
+    from mcav import nn as N
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + C)
+    pre_x = torch.randn(B, C, H, W, generator=g).requires_grad_()
+    x = F.elu(pre_x)                                          # the head's input is an ELU output (decoder conv (i, 1))
+    w = (torch.randn(1, C, 3, 3, generator=g) * 0.2).requires_grad_()
+    b = (0.1 * torch.randn(1, generator=g)).requires_grad_()
+    disp = torch.sigmoid(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b))
+    ddisp = torch.randn(disp.shape, generator=g)
+    addend = torch.randn(B, C, H, W, generator=g)
+    disp.backward(ddisp)
+    want_dx = pre_x.grad + addend                             # gradient at the pre-activation of x, plus the other branch's
+
+    wp, bp = torch.nn.Parameter(w.detach().to(DEV)), torch.nn.Parameter(b.detach().to(DEV))
+    spec = N.ConvSpec(wp, bp, 1, 1, N.PAD_REFLECT)
+    xd = nhwc(x.detach())
+    assert N.narrow_ok(spec, xd)
+    got = N.conv3x3r_c1_fwd(spec, xd, N.ACT_SIGMOID)
+    assert rel_err(nchw(got), disp) < 2e-5
+    dx = N.conv3x3r_c1_bwd(spec, xd, nhwc(ddisp), got, N.ACT_SIGMOID, N.ACT_ELU, addend=nhwc(addend))
+    assert rel_err(nchw(dx), want_dx) < 2e-5
+    assert rel_err(wp.grad, w.grad) < 5e-5 and rel_err(bp.grad, b.grad) < 5e-5
+    N.conv3x3r_c1_bwd(spec, xd, nhwc(ddisp), got, N.ACT_SIGMOID, N.ACT_ELU)       # accumulates into .grad; no addend
+    assert rel_err(wp.grad, 2 * w.grad) < 5e-5

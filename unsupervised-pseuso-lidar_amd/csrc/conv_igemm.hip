@@ -571,7 +571,11 @@ __device__ __forceinline__ f32x4 buf_load4s(__amdgpu_buffer_rsrc_t r, unsigned b
 
 constexpr int TAB_TAPS = 9;
 
-template <class T>
+// REFL = the adjoint of the 3x3 reflection-padded conv (decoder dgrad): away from the image border it is the plain
+// correlation (sy = dy + 1 - ky); a wavefront that owns rows within two pixels of the border (wave-uniform test) issues up
+// to three more loads per row -- the outputs whose reflected tap landed on this pixel -- and adds them when the tile is
+// written to LDS, one iteration later, so they cost no extra wait.
+template <class T, bool REFL>
 __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     constexpr int BM = T::BM, BN = T::BN, CKT = T::KD;
     __shared__ __attribute__((aligned(16))) float As[2][BM][T::LD];
@@ -616,7 +620,10 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
         const int n = s_rn[r], dy = s_ry[r], dx = s_rx[r];
         int sy, sx;
         bool ok = n >= 0;
-        if (g.mode == MCAV_G_ADJ_STRIDE2) {
+        if (REFL) {
+            sy = dy + 1 - ky;
+            sx = dx + 1 - kx;
+        } else if (g.mode == MCAV_G_ADJ_STRIDE2) {
             const int ty = dy + g.offset - ky, tx = dx + g.offset - kx;      // x[d] collects dy[(d + pad - k) / 2] when whole
             ok = ok && ty >= 0 && tx >= 0 && (((ty | tx) & 1) == 0);
             sy = ty >> 1; sx = tx >> 1;
@@ -654,6 +661,18 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
         const bool ok = nn < BN && n0 + nn < p.n_count;
         boff[j] = ok ? (unsigned)(((p.n_begin + n0 + nn) * p.Kstride + cb * 4) * 4) : OOB;
     }
+    bool wave_border = false;
+    if constexpr (REFL) {
+        bool bd = false;
+#pragma unroll
+        for (int j = 0; j < T::AROWS; ++j) {
+            const int r = r0 + T::RPP * j;
+            const int y = s_ry[r], x = s_rx[r];
+            bd = bd || (s_rn[r] >= 0 && (y <= 1 || y >= g.Hs - 2 || x <= 1 || x >= g.Ws - 2));
+        }
+        wave_border = __any(bd);
+    }
+    f32x4 ex0[REFL ? T::AROWS : 1], ex1[REFL ? T::AROWS : 1], ex2[REFL ? T::AROWS : 1];
     int ti = 0, chunk = 0;                       // the ISSUE pointer: next K-tile to load
     int tap = __builtin_amdgcn_readfirstlane(s_tl[0]);
     unsigned oa[T::AROWS], ob[T::AROWS];
@@ -674,6 +693,27 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
 #pragma unroll
             for (int j = 0; j < T::AROWS; ++j) ra[j] = buf_load4s(rs2, ob[j], (cbase - g.C1) * 4);
         }
+        if constexpr (REFL) {
+            if (wave_border) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                for (int j = 0; j < T::AROWS; ++j) {
+                    const int r = r0 + T::RPP * j;
+                    const int n = s_rn[r], dy = s_ry[r], dx = s_rx[r];
+                    const int sy = dy + 1 - ky, sx = dx + 1 - kx;
+                    const int ey = (dy == 1 && ky == 0) ? 0 : ((dy == g.Hs - 2 && ky == 2) ? g.Hs - 1 : -1);
+                    const int ex = (dx == 1 && kx == 0) ? 0 : ((dx == g.Ws - 2 && kx == 2) ? g.Ws - 1 : -1);
+                    const bool syok = (unsigned)sy < (unsigned)g.Hs, sxok = (unsigned)sx < (unsigned)g.Ws;
+                    const int rowb = n * g.Hs, cb = c4 * 4;
+                    const unsigned a0 = (unsigned)((((rowb + ey) * g.Ws + sx) * g.C1 + cb) * 4);
+                    const unsigned a1 = (unsigned)((((rowb + sy) * g.Ws + ex) * g.C1 + cb) * 4);
+                    const unsigned a2 = (unsigned)((((rowb + ey) * g.Ws + ex) * g.C1 + cb) * 4);
+                    ex0[j] = buf_load4s(rs1, (n >= 0 && ey >= 0 && sxok) ? a0 : OOB, cbase * 4);
+                    ex1[j] = buf_load4s(rs1, (n >= 0 && ex >= 0 && syok) ? a1 : OOB, cbase * 4);
+                    ex2[j] = buf_load4s(rs1, (n >= 0 && ey >= 0 && ex >= 0) ? a2 : OOB, cbase * 4);
+                }
+            }
+        }
         const int kb = (tap * p.Kp + cbase) * 4;
 #pragma unroll
         for (int j = 0; j < T::BVECS; ++j) rb[j] = buf_load4s(rsw, boff[j], kb);
@@ -685,8 +725,14 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
         }
     };
     constexpr bool BFULL = (BN * T::LPR) % 256 == 0;             // every thread owns a B piece: no predicated LDS write in the loop
-    auto store = [&](const f32x4 (&ra)[T::AROWS], const f32x4 (&rb)[T::BVECS], auto bufc) {
+    auto store = [&](f32x4 (&ra)[T::AROWS], const f32x4 (&rb)[T::BVECS], auto bufc) {
         constexpr int buf = decltype(bufc)::value;
+        if constexpr (REFL) {
+            if (wave_border) {
+#pragma unroll
+                for (int j = 0; j < T::AROWS; ++j) ra[j] += (ex0[j] + ex1[j]) + ex2[j];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < T::AROWS; ++j) *reinterpret_cast<f32x4*>(&As[buf][r0 + T::RPP * j][c4 * 4]) = ra[j];
 #pragma unroll
@@ -1030,6 +1076,231 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         }
 }
 
+// Table-driven weight-gradient kernel: same GEMM, tiling, LDS panels and epilogue as wgrad_kernel, with the addressing taken
+// out of the K loop (the GEMM's reduction runs over PIXELS here, so every K-tile needs fresh source addresses):
+//   * once per workgroup, the source byte offset of every (pixel of this split, filter tap touched by this row tile) goes to
+//     an LDS table -- padding, reflection, stride, upsampling are resolved there, invalid taps hold an out-of-range offset;
+//   * per A load the loop does one ds_read_b32 (prefetched a tile ahead) and one v_add (the lane's channel offset);
+//   * dy rows advance linearly: their loads use the instruction's SCALAR offset, and the buffer resource ends at this
+//     split's last pixel, so the ragged last tile needs no masking.
+// The host sizes the splits so that the table fits (WG_TABCAP entries); otherwise the general kernel runs.
+constexpr int WG_TABCAP = 4096;
+
+template <class T>
+__global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
+    constexpr int BM = T::BM, BN = T::BN;
+    __shared__ __attribute__((aligned(16))) float Xs[2][KP][BM];
+    __shared__ __attribute__((aligned(16))) float Ys[2][KP][BN];
+    __shared__ unsigned s_tab[WG_TABCAP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per_split = p.mtiles * p.ntiles;
+    const int split = blockIdx.x / per_split, rem = blockIdx.x - split * per_split;
+    const int nt = rem % p.ntiles, mt = rem / p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const GatherSrc& g = p.g;
+
+    constexpr int ACOLS = BM / 4, APIX = 256 / ACOLS, APASS = KP / APIX, CPW = ACOLS / 4;
+    const int acol = wave * CPW + lane % CPW, apix = lane / CPW;
+    const int kflat = m0 + acol * 4;
+    constexpr int BCOLS = BN / 4;
+    constexpr int BPIX = 256 / BCOLS > KP ? KP : 256 / BCOLS;
+    constexpr int BPASS = KP / BPIX;
+    const int bcol = tid % BCOLS, bpix = tid / BCOLS;
+
+    const int pix_begin = split * p.pix_per_split;
+    const int pix_end = min(p.Mpix, pix_begin + p.pix_per_split);
+    const int T_total = pix_end > pix_begin ? (pix_end - pix_begin + KP - 1) / KP : 0;
+    const int npx = T_total * KP;                         // table entries per tap (rows past pix_end are out of range)
+    const int tap_lo = m0 / p.Kp;
+    const int tap_hi = min(p.taps - 1, (m0 + BM - 1) / p.Kp);
+    const int NT = tap_hi - tap_lo + 1;
+    const bool two = g.C2 > 0;                            // second table: offsets into x2 (x1 may be the upsampled source)
+
+    // ---- table: [source][tap - tap_lo][pixel - pix_begin]
+    for (int pl = tid; pl < npx; pl += 256) {
+        const int m = pix_begin + pl;
+        const bool live = m < pix_end;
+        const int n = m / (p.Hd * p.Wd);
+        const int r = m - n * (p.Hd * p.Wd);
+        const int dy = r / p.Wd, dx = r - dy * p.Wd;
+        for (int tl = 0; tl < NT; ++tl) {
+            const int tap = tap_lo + tl;
+            const int ky = tap / p.kw, kx = tap - ky * p.kw;
+            int sy = dy * g.stride + ky + g.offset, sx = dx * g.stride + kx + g.offset;      // sign = +1 (forward gather)
+            if (g.pad_mode == MCAV_PAD_REFLECT) {
+                sy = reflect_idx(sy, g.Hs);
+                sx = reflect_idx(sx, g.Ws);
+            }
+            const bool ok = live && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
+            const int pix = (n * g.Hs + sy) * g.Ws + sx;
+            const int pix1 = g.up1 ? ((n * (g.Hs >> 1) + (sy >> 1)) * (g.Ws >> 1) + (sx >> 1)) : pix;
+            s_tab[tl * npx + pl] = ok ? (unsigned)(pix1 * g.C1) * 4u : OOB;
+            if (two) s_tab[(NT + tl) * npx + pl] = ok ? (unsigned)(pix * g.C2) * 4u : OOB;
+        }
+    }
+
+    // ---- this thread's A column: filter tap and channel; a wavefront's columns lie in one source
+    int tl_own = 0, ac = 0;
+    bool a_ok = false;
+    if (kflat < p.Ktot) {
+        const int tap = kflat / p.Kp;
+        ac = kflat - tap * p.Kp;
+        tl_own = tap - tap_lo;
+        a_ok = tap < p.taps;
+    }
+    const bool use2 = __builtin_amdgcn_readfirstlane((int)(two && ac >= g.C1)) != 0;
+    const unsigned bytes1 = (unsigned)((size_t)g.B * (g.up1 ? (g.Hs >> 1) * (g.Ws >> 1) : g.Hs * g.Ws) * g.C1 * 4);
+    const unsigned bytes2 = (unsigned)((size_t)g.B * g.Hs * g.Ws * g.C2 * 4);
+    const __amdgpu_buffer_rsrc_t rsx = use2 ? make_rsrc(g.x2, bytes2) : make_rsrc(g.x1, bytes1);
+    const __amdgpu_buffer_rsrc_t rsy = make_rsrc(p.dy, (unsigned)((size_t)pix_end * p.Cdy * 4));      // ends at this split's last pixel
+    const int acc_ = use2 ? ac - g.C1 : ac;
+    a_ok = a_ok && acc_ < (use2 ? g.C2 : g.C1);
+    // Lanes on K-padding channels or on rows past Ktot add the out-of-range bit: they read zero (or, under an out-of-image tap whose
+    // table entry carries the same bit, whatever sits at the wrapped offset) into GEMM rows that nothing consumes.
+    const unsigned chan = a_ok ? (unsigned)acc_ * 4u : OOB;
+    const unsigned* trow = &s_tab[((use2 ? NT : 0) + (a_ok ? tl_own : 0)) * npx + apix];
+    unsigned boff[BPASS];
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+        const int pl = bpix + j * BPIX, c = n0 + bcol * 4;
+        const bool ok = pl < KP && c + 4 <= p.CoutLoad;
+        boff[j] = ok ? (unsigned)(((pix_begin + pl) * p.Cdy + p.dy_choff + c) * 4) : OOB;
+    }
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.want_bias && mt == 0;
+    __syncthreads();
+
+    unsigned toff[APASS];                                 // table values of the next tile to issue
+    int u = 0;                                            // the issue pointer
+    auto fetch = [&]() {
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) toff[j] = trow[u * KP + j * APIX];
+    };
+    auto issue = [&](f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) ra[j] = buf_load4(rsx, toff[j] + chan);
+        const int sb = u * KP * p.Cdy * 4;
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) rb[j] = buf_load4s(rsy, boff[j], sb);
+        ++u;
+        if (u < T_total) fetch();
+    };
+    auto store = [&](const f32x4 (&ra)[APASS], const f32x4 (&rb)[BPASS], auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < BPASS; ++j) bsum += rb[j];
+        }
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) *reinterpret_cast<f32x4*>(&Xs[buf][apix + j * APIX][acol * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            const int pl = bpix + j * BPIX;
+            if (BPIX * BPASS == KP || pl < KP) *reinterpret_cast<f32x4*>(&Ys[buf][pl][bcol * 4]) = rb[j];
+        }
+    };
+
+    const int wm0 = (wave / T::WAVES_N) * T::WM, wn0 = (wave % T::WAVES_N) * T::WN;
+    typename T::AccT acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < T::ACC; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int MFR = T::MF;
+    constexpr int KSTEP = MFR == 32 ? 2 : 4;              // pixels consumed per MFMA
+    const int fr = lane & (MFR - 1), fk = lane / MFR;
+    auto compute = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        constexpr int NB = KP / KSTEP / 4;                // batches of 4 MFMA k-steps; batch b + 1 is read before batch b is issued
+        float a[2][4][T::TM], b[2][4][T::TN];
+        auto rd = [&](int s, int k0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i) a[s][q][i] = Xs[buf][(k0 + q) * KSTEP + fk][wm0 + i * MFR + fr];
+#pragma unroll
+                for (int j = 0; j < T::TN; ++j) b[s][q][j] = Ys[buf][(k0 + q) * KSTEP + fk][wn0 + j * MFR + fr];
+            }
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            if (bt + 1 < NB) rd((bt + 1) & 1, (bt + 1) * 4);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::TN; ++j) {
+                        if constexpr (MFR == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[bt & 1][q][i], b[bt & 1][q][j], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[bt & 1][q][i], b[bt & 1][q][j], acc[i][j], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    f32x4 ra[APASS], rb[BPASS];
+    auto step = [&](auto cur, auto nxt) {
+        store(ra, rb, nxt);
+        issue(ra, rb);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    };
+    int t = 0;
+    if (T_total > 0) {
+        fetch();
+        issue(ra, rb);
+        store(ra, rb, B0{});
+        if (T_total > 1) issue(ra, rb);
+    }
+    __syncthreads();
+    for (; t + 3 < T_total; t += 2) {
+        step(B0{}, B1{});
+        step(B1{}, B0{});
+    }
+    for (; t < T_total; ++t) {
+        if (t & 1) {
+            if (t + 1 < T_total) { store(ra, rb, B0{}); if (t + 2 < T_total) issue(ra, rb); }
+            compute(B1{});
+        } else {
+            if (t + 1 < T_total) { store(ra, rb, B1{}); if (t + 2 < T_total) issue(ra, rb); }
+            compute(B0{});
+        }
+        __syncthreads();
+    }
+
+    constexpr int MF = T::MF;
+    const int ccol = lane & (MF - 1);
+    float* slab = p.slab + (size_t)split * (p.Ktot + 1) * p.slabN;
+    if (do_bias) {
+        if (bpix < BPIX) *reinterpret_cast<f32x4*>(&Ys[0][bpix][bcol * 4]) = bsum;
+        __syncthreads();
+        if (tid < BN) {
+            float tsum = 0.f;
+            for (int k = 0; k < BPIX; ++k) tsum += Ys[0][k][tid];
+            if (n0 + tid < p.slabN) slab[(size_t)p.Ktot * p.slabN + n0 + tid] = tsum;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) {
+            const int n = n0 + wn0 + j * MF + ccol;
+#pragma unroll
+            for (int r = 0; r < T::ACC; ++r) {
+                const int row = m0 + wm0 + i * MF + (MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) : 4 * (lane >> 4) + r);
+                if (row < p.Ktot && n < p.slabN) slab[(size_t)row * p.slabN + n] = acc[i][j][r];
+            }
+        }
+}
+
 // First reduction level when there are many pixel splits: dst[g][e] = sum of the splits of group g (fixed order).
 __global__ __launch_bounds__(256) void wgrad_presum_kernel(const float* slab, int splits, size_t elems, int per_group, float* dst) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1214,7 +1485,10 @@ inline void launch_igemm(const IgemmParams& p, hipStream_t s) {
     const bool fast_mode = p.g.mode == MCAV_G_DIRECT || (p.g.mode == MCAV_G_ADJ_STRIDE2 && p.g.C2 == 0) || p.g.mode == MCAV_G_SMALLC;
     const bool tab = (p.g.mode == MCAV_G_DIRECT || (p.g.mode == MCAV_G_ADJ_STRIDE2 && p.g.C2 == 0)) && c4ok && p.taps <= TAB_TAPS &&
                      p.g.C1 + p.g.C2 == p.Kp && p.Kp % T::KD == 0 && (p.g.C2 == 0 || p.g.C1 % T::KD == 0) && !p.no_tab;
-    if (tab) igemm_tab_kernel<T><<<grid, 256, 0, s>>>(p);
+    // (tall tiles put rows of many image lines into one wavefront: most wavefronts would take the border path, so they keep the general kernel)
+    const bool tab_refl = p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0 && p.g.C1 == p.Kp && p.Kp % T::KD == 0 && !p.no_tab && T::AROWS <= 2;
+    if (tab) igemm_tab_kernel<T, false><<<grid, 256, 0, s>>>(p);
+    else if (tab_refl) igemm_tab_kernel<T, true><<<grid, 256, 0, s>>>(p);
     else if (fast_mode && c4ok) igemm_kernel<T, K_FAST><<<grid, 256, 0, s>>>(p);
     else if (p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0) igemm_kernel<T, K_REFLADJ><<<grid, 256, 0, s>>>(p);
     else igemm_kernel<T, K_GENERIC><<<grid, 256, 0, s>>>(p);
@@ -1258,6 +1532,7 @@ namespace mcav {
 struct WgradPlan {
     WgradParams p;
     int tile;
+    bool use_tab;
     size_t slab_bytes, pre_bytes;
     int ci_t, groups, per_group;
 };
@@ -1281,7 +1556,7 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     if ((long)d->B * d->Hs * d->Ws * (d->C1 > d->C2 ? d->C1 : d->C2) * 4 >= 0x7fffffffL || M * d->Cdy * 4 >= 0x7fffffffL) return false;
     p.Mpix = (int)M;
     p.slabN = round_up(d->Cout, 16);
-    int tile = d->tile;
+    int tile = d->tile & 0xff;
     if (!tile) {
         if (d->Cout <= 16) tile = round_up(p.Ktot, 64) < round_up(p.Ktot, 256) ? 6 : 4;
         else if (d->Cout <= 32) tile = (d->C2 > 0 && d->C1 % 64 != 0) ? 7 : 3;
@@ -1300,6 +1575,24 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     if (splits > 512) splits = 512;
     if (splits < 1) splits = 1;
     p.pix_per_split = round_up((p.Mpix + splits - 1) / splits, KP);
+    // table-driven kernel: the per-workgroup offset table (pixels of a split x taps touched by a row tile x sources) must fit
+    pl.use_tab = false;
+    const int wave_ch = BM / 4;
+    const bool fast = d->mode == MCAV_G_DIRECT && (d->C1 & 3) == 0 && (d->C2 & 3) == 0 && (d->C2 == 0 || d->C1 % wave_ch == 0) &&
+                      (p.CoutLoad & 3) == 0 && (d->Cdy & 3) == 0 && (d->dy_choff & 3) == 0 && !((d->tile >> 8) & 1);
+    if (fast) {
+        int ntmax = 1;
+        for (int mt = 0; mt < p.mtiles; ++mt) {
+            const int lo = mt * BM / d->Kp, hi = (mt * BM + BM - 1) / d->Kp < p.taps - 1 ? (mt * BM + BM - 1) / d->Kp : p.taps - 1;
+            if (hi - lo + 1 > ntmax) ntmax = hi - lo + 1;
+        }
+        const int cap_pix = WG_TABCAP / (ntmax * (d->C2 > 0 ? 2 : 1)) / KP * KP;
+        if (cap_pix >= 8 * KP) {
+            int pps = p.pix_per_split < cap_pix ? p.pix_per_split : cap_pix;
+            const int need = (p.Mpix + pps - 1) / pps;
+            if (need <= 512) { p.pix_per_split = pps; pl.use_tab = true; }
+        }
+    }
     p.splits = (p.Mpix + p.pix_per_split - 1) / p.pix_per_split;
     p.want_bias = d->dbias != nullptr;
     pl.slab_bytes = align_up(sizeof(float) * (size_t)p.splits * (p.Ktot + 1) * p.slabN, 256);
@@ -1317,8 +1610,9 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
 }
 
 template <class T>
-inline void launch_wgrad(const WgradParams& p, hipStream_t s) {
+inline void launch_wgrad(const WgradParams& p, bool use_tab, hipStream_t s) {
     const int grid = p.splits * p.mtiles * p.ntiles;
+    if (use_tab) { wgrad_tab_kernel<T><<<grid, 256, 0, s>>>(p); return; }
     const int wave_ch = T::BM / 4;          // channels one wavefront's A columns span
     const bool fast = (p.g.mode == MCAV_G_DIRECT || p.g.mode == MCAV_G_SMALLC) && (p.g.C1 & 3) == 0 && (p.g.C2 & 3) == 0 && (p.g.C2 == 0 || p.g.C1 % wave_ch == 0) &&
                       (p.CoutLoad & 3) == 0 && (p.Cdy & 3) == 0 && (p.dy_choff & 3) == 0 && p.Wd >= 16;
@@ -1341,12 +1635,12 @@ MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t wor
     hipStream_t s = as_stream(stream);
     pl.p.slab = reinterpret_cast<float*>(workspace);
     switch (pl.tile) {
-        case 1: launch_wgrad<Tile128x64>(pl.p, s); break;
-        case 2: launch_wgrad<Tile64x64>(pl.p, s); break;
-        case 3: launch_wgrad<Tile256x32>(pl.p, s); break;
-        case 4: launch_wgrad<Tile256x16>(pl.p, s); break;
-        case 6: launch_wgrad<Tile64x16>(pl.p, s); break;
-        case 7: launch_wgrad<Tile128x32>(pl.p, s); break;
+        case 1: launch_wgrad<Tile128x64>(pl.p, pl.use_tab, s); break;
+        case 2: launch_wgrad<Tile64x64>(pl.p, pl.use_tab, s); break;
+        case 3: launch_wgrad<Tile256x32>(pl.p, pl.use_tab, s); break;
+        case 4: launch_wgrad<Tile256x16>(pl.p, pl.use_tab, s); break;
+        case 6: launch_wgrad<Tile64x16>(pl.p, pl.use_tab, s); break;
+        case 7: launch_wgrad<Tile128x32>(pl.p, pl.use_tab, s); break;
         default: return MCAV_E_INVALID;
     }
     const dim3 rgrid((d->Cout + 31) / 32, (d->Cin + pl.ci_t - 1) / pl.ci_t);

@@ -161,7 +161,8 @@ def decoder_forward(dec, feats, scales=(0,)):
         b = N.conv_fwd(dec_spec(dec.conv("upconv", i, 1).conv.conv), a, feats[i - 1] if i > 0 else None, up1=True, act=N.ACT_ELU)
         sv["a"][i], sv["b"][i] = a, b
         if i in scales:
-            sv["disp"][i] = N.conv_fwd(dec_spec(dec.conv("dispconv", i).conv), b, act=N.ACT_SIGMOID)
+            sd = dec_spec(dec.conv("dispconv", i).conv)
+            sv["disp"][i] = N.conv3x3r_c1_fwd(sd, b, N.ACT_SIGMOID) if N.narrow_ok(sd, b) else N.conv_fwd(sd, b, act=N.ACT_SIGMOID)
         x = b
     return sv["disp"], sv
 
@@ -177,11 +178,15 @@ def decoder_backward(dec, sv, ddisp, need_feature_grads=True):
         s10 = dec_spec(dec.conv("upconv", i, 0).conv.conv)
         if i in ddisp and ddisp[i] is not None:
             sd = dec_spec(dec.conv("dispconv", i).conv)
-            # sigmoid'(disp) * d disp, stored as channel 0 of a zeroed 4-channel map so the 16-byte gathers apply
-            dpre_d = N.act_bwd_padded(ddisp[i], sv["disp"][i], N.ACT_SIGMOID, 4)
-            N.conv_wgrad(sd, b, dpre_d)
-            # d b_i from the disparity head, through ELU'(b_i); joins what came from level i-1 (addend)
-            dpre_b = N.conv_dgrad(sd, dpre_d, hw(b), dact_aux=b, dact=N.ACT_ELU, addend=dpre_b)
+            if N.narrow_ok(sd, b):
+                # one pass over b_i: sigmoid', the head's weight / bias gradients, and d b_i through ELU'(b_i) (+ what came from level i-1)
+                dpre_b = N.conv3x3r_c1_bwd(sd, b, ddisp[i], sv["disp"][i], N.ACT_SIGMOID, N.ACT_ELU, addend=dpre_b)
+            else:
+                # sigmoid'(disp) * d disp, stored as channel 0 of a zeroed 4-channel map so the 16-byte gathers apply
+                dpre_d = N.act_bwd_padded(ddisp[i], sv["disp"][i], N.ACT_SIGMOID, 4)
+                N.conv_wgrad(sd, b, dpre_d)
+                # d b_i from the disparity head, through ELU'(b_i); joins what came from level i-1 (addend)
+                dpre_b = N.conv_dgrad(sd, dpre_d, hw(b), dact_aux=b, dact=N.ACT_ELU, addend=dpre_b)
         if dpre_b is None:
             raise RuntimeError("decoder_backward: no gradient reaches level %d" % i)
         skip = feats[i - 1] if i > 0 else None

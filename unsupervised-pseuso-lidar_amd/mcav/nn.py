@@ -54,6 +54,9 @@ L.register({
     "mcav_maxpool3s2_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "mcav_act_bwd": (c_i, [c_p, c_p, c_i, c_sz, c_p, c_i, c_p]),
     "mcav_act_bwd_strided": (c_i, [c_p, c_p, c_i, c_sz, c_p, c_i, c_p]),
+    "mcav_conv3x3r_c1_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p]),
+    "mcav_conv3x3r_c1_bwd_workspace_bytes": (c_sz, [c_i]),
+    "mcav_conv3x3r_c1_bwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_sz, c_p]),
     "mcav_add": (c_i, [c_p, c_p, c_sz, c_p, c_p]),
     "mcav_spatial_mean": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "mcav_spatial_mean_bwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
@@ -294,14 +297,66 @@ def conv_wgrad(spec, x1, dy, x2=None, up1=False, tile=0):
     d.Cout, d.Cin = spec.cout, spec.cin
     d.dw_oihw, d.accumulate, d.dbias = P(gw), 1, P(gb)
     d.tile = tile
+    flops = 2.0 * B * dy.shape[1] * dy.shape[2] * spec.cout * spec.cin * spec.kh * spec.kw
+    tag = "pix=%d Cout=%d Ktot=%dx%d s%d" % (B * dy.shape[1] * dy.shape[2], spec.cout, spec.cin, spec.kh * spec.kw, spec.stride)
+    launch_wgrad(d, (x1, x2, dy), flops, tag)
+
+
+class _WgradSide:
+    """Weight-gradient launches go to a second HIP stream.
+
+    Inside a backward pass the wgrad of a layer only feeds the optimiser, while its dgrad feeds the next layer: the wgrad chain
+    (GEMM + slab reductions, about a third of the step) runs concurrently with the dgrad chain of the main stream, so that
+    the ramp-up, tail and launch gap of one kernel are filled with the other chain's workgroups.  The fork is an event wait
+    per launch, the join is queued on the autograd engine as an end-of-backward callback (the mechanism DDP uses), so
+    `.grad` is complete on the caller's stream when `backward()` returns.  Both are captured by a hipGraph as parallel
+    branches.  Outside a backward pass (direct calls, tests, micro-benchmarks) launches stay on the caller's stream."""
+
+    def __init__(self):
+        self.enabled = True
+        self.stream = None
+        self.keep = []
+        self.forked = False
+
+    def run(self, fn, tensors):
+        if not self.enabled or PROFILE is not None or not tensors[0].is_cuda:
+            return fn()
+        if not self.forked:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.join)
+            except RuntimeError:             # not inside a backward pass
+                return fn()
+            self.forked = True
+            self.main = torch.cuda.current_stream()
+            if self.stream is None or self.stream.device != self.main.device:
+                self.stream = torch.cuda.Stream(device=self.main.device)
+        self.stream.wait_stream(self.main)
+        with torch.cuda.stream(self.stream):
+            fn()
+        self.keep.append(tensors)            # the main stream's allocator must not recycle these before the join
+
+    def join(self):
+        if self.forked:
+            self.main.wait_stream(self.stream)
+            self.keep.clear()
+            self.forked = False
+
+
+WGRAD_SIDE = _WgradSide()
+
+
+def launch_wgrad(d, tensors, flops=0.0, tag=""):
+    """mcav_wgrad for a filled descriptor (workspace handling + stream choice).  tensors: what the launch reads."""
     h = L.lib()
     nbytes = h.mcav_wgrad_workspace_bytes(ctypes.byref(d))
     if nbytes == 0:
         raise L.MCAVError("mcav_wgrad: invalid descriptor")
-    ws = L.workspace(nbytes, x1.device, "wgrad")
-    with _Timed("wgrad", 2.0 * B * dy.shape[1] * dy.shape[2] * spec.cout * spec.cin * spec.kh * spec.kw,
-                "pix=%d Cout=%d Ktot=%dx%d s%d" % (B * dy.shape[1] * dy.shape[2], spec.cout, spec.cin, spec.kh * spec.kw, spec.stride)):
-        L.check(h.mcav_wgrad(ctypes.byref(d), P(ws), ws.numel(), L.stream()), "mcav_wgrad")
+
+    def go():
+        ws = L.workspace(nbytes, tensors[0].device, "wgrad")
+        with _Timed("wgrad", flops, tag):
+            L.check(h.mcav_wgrad(ctypes.byref(d), P(ws), ws.numel(), L.stream()), "mcav_wgrad")
+    WGRAD_SIDE.run(go, tensors)
 
 
 def grad_buffer(param):
@@ -427,6 +482,35 @@ def act_bwd_padded(dy, y, act, cp):
     out = torch.zeros((B, H, W, cp), dtype=torch.float32, device=y.device)
     L.check(L.lib().mcav_act_bwd_strided(P(dy), P(y), act, y.numel(), P(out), cp, L.stream()), "mcav_act_bwd_strided")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ one-channel 3x3 heads
+def narrow_ok(spec, x):
+    """The disparity-head shape the stencil kernels cover: 3x3, stride 1, reflection pad 1, one output channel."""
+    return (spec.cout == 1 and spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad == 1 and spec.pad_mode == PAD_REFLECT
+            and x.shape[3] == spec.cin and spec.cin in (16, 32, 64, 128) and x.shape[1] >= 2 and x.shape[2] >= 2)
+
+
+def conv3x3r_c1_fwd(spec, x, act):
+    B, H, W, C = x.shape
+    y = empty((B, H, W, 1), x)
+    with _Timed("fwd", 2.0 * B * H * W * C * 9, "head M=%d N=1 K=%dx9 %dx%d" % (B * H * W, C, H, W)):
+        L.check(L.lib().mcav_conv3x3r_c1_fwd(P(x), B, H, W, C, P(spec.weight), P(spec.bias), act, P(y), L.stream()), "mcav_conv3x3r_c1_fwd")
+    return y
+
+
+def conv3x3r_c1_bwd(spec, x, dy, y, act, x_act, addend=None):
+    """Fused backward of the head: -> dx = adjoint(dy * act'(y)) * x_act'(x) + addend; accumulates weight / bias gradients."""
+    B, H, W, C = x.shape
+    h = L.lib()
+    ws = L.workspace(h.mcav_conv3x3r_c1_bwd_workspace_bytes(C), x.device, "narrow")
+    dx = torch.empty_like(x)
+    gw = grad_buffer(spec.weight)
+    gb = grad_buffer(spec.bias) if spec.bias is not None else None
+    with _Timed("dgrad", 4.0 * B * H * W * C * 9, "head bwd (dgrad+wgrad) M=%d K=%dx9 %dx%d" % (B * H * W, C, H, W)):
+        L.check(h.mcav_conv3x3r_c1_bwd(P(x), B, H, W, C, P(spec.weight), P(dy), P(y), act, x_act, P(addend), P(dx), P(gw), P(gb), 1,
+                                       P(ws), ws.numel(), L.stream()), "mcav_conv3x3r_c1_bwd")
+    return dx
 
 
 def add(a, b):

@@ -111,9 +111,7 @@ def deconv(tape, ds, x, out_hw, act=N.ACT_RELU):
         wd.dy, wd.Hd, wd.Wd, wd.Cdy, wd.dy_choff = P(x), Hs, Ws, C, 0
         wd.Cout, wd.Cin = ds.cin, ds.cout
         wd.dw_oihw, wd.accumulate, wd.dbias, wd.tile = P(gw), 1, None, 0
-        h = L.lib()
-        ws = L.workspace(h.mcav_wgrad_workspace_bytes(ctypes.byref(wd)), x.device, "wgrad")
-        L.check(h.mcav_wgrad(ctypes.byref(wd), P(ws), ws.numel(), L.stream()), "mcav_wgrad(deconv)")
+        N.launch_wgrad(wd, (dpre, x))
         colsum(dpre, N.grad_buffer(ds.bias), accumulate=True)
         # data gradient: the ordinary stride-2 conv of dpre with the same weights (O = Cin)
         tape.add_grad(x, N.conv_fwd(spec, dpre))
