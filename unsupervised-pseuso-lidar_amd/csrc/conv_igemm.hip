@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
 #pragma unroll
         for (int j = 0; j < BPASS; ++j) {
             const int pl = bpix + j * BPIX;
-            if (BPIX * BPASS == KP || pl < KP) *reinterpret_cast<f32x4*>(&Ys[buf][pl][bcol * 4]) = rb[j];
+            if (256 / BCOLS <= KP || pl < KP) *reinterpret_cast<f32x4*>(&Ys[buf][pl][bcol * 4]) = rb[j];      // narrow N: idle threads past KP rows
         }
     };
 
