@@ -68,10 +68,16 @@ def make_step(depth, pose, opt, crit, samples, pair=True, graph=False):
     from mcav import dist as mdist
     tgt, refs, K = samples["tgt"], samples["ref_imgs"], samples["intrinsics"]
 
-    def fwd_bwd(tgt, ref0, ref1, K):
+    from mcav import nn as N
+    from mcav.streams import Branch
+    pose_branch = Branch()
+
+    def fwd_bwd(tgt, ref0, ref1, K):          # the sequence of Trainer.process_batch (unsupervised-pseuso-lidar_amd/trainer.py)
         opt.zero_grad()
+        N.refresh_packed_weights(tgt.device)                               # both streams read the packed filters
+        poses = pose_branch.fork(pose, tgt, [ref0, ref1])                  # independent of the depth net until the loss: second stream
         disps = list(depth.forward_pair(tgt, ref0)) if pair else [depth(tgt), depth(ref0)]
-        poses = pose(tgt, [ref0, ref1])
+        poses = pose_branch.join(poses)
         loss = crit.forward(tgt, [ref0, ref1], disps, poses, K, None)
         sum(loss).backward()
         return tuple(loss)

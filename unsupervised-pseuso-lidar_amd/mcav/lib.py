@@ -94,8 +94,8 @@ _WS = {}
 
 
 def workspace(nbytes, device, key="default"):
-    """A cached byte workspace per (device, key); grown on demand, reused across calls on one stream."""
-    k = (str(device), key)
+    """A cached byte workspace per (device, key, stream); grown on demand, reused across calls on that stream."""
+    k = (str(device), key, torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0)   # one per stream: streams overlap
     buf = _WS.get(k)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)

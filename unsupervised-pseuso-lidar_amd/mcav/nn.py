@@ -159,6 +159,18 @@ class PackRegistry:
 PACKS = PackRegistry()
 
 
+def refresh_packed_weights(device):
+    """Re-derive every stale packed filter copy NOW, on the current stream.  Call before forking work onto other streams: the lazy
+    refresh inside packed_fwd()/packed_bwd() runs on whichever stream asks first, which the other streams would not wait for."""
+    for ref, tr in PACKS.entries:
+        s = ref()
+        if s is None or s.weight.device != device:
+            continue
+        if (s._key_b if tr else s._key_f) != s._key():
+            PACKS.repack_all(device)
+            return
+
+
 class ConvSpec:
     """Static description of one convolution + the packed copies of its weight (kept fresh lazily)."""
 
@@ -309,37 +321,59 @@ class _WgradSide:
     (GEMM + slab reductions, about a third of the step) runs concurrently with the dgrad chain of the main stream, so that
     the ramp-up, tail and launch gap of one kernel are filled with the other chain's workgroups.  The fork is an event wait
     per launch, the join is queued on the autograd engine as an end-of-backward callback (the mechanism DDP uses), so
-    `.grad` is complete on the caller's stream when `backward()` returns.  Both are captured by a hipGraph as parallel
-    branches.  Outside a backward pass (direct calls, tests, micro-benchmarks) launches stay on the caller's stream."""
+    `.grad` is complete on the caller's stream when `backward()` returns.  Outside a backward pass (direct calls, tests,
+    micro-benchmarks) launches stay on the caller's stream.
+
+    The same callback also joins every stream a network's backward ran on (autograd replays a backward node on the stream of
+    its forward, e.g. the pose branch of mcav/streams.py) with the stream `backward()` was called from: the engine only does
+    that for gradients it accumulates itself, and these networks write their parameter gradients straight into the arena."""
 
     def __init__(self):
         self.enabled = True
         self.stream = None
         self.keep = []
+        self.mains = []            # streams a network backward ran on during this backward pass
+        self.in_backward = False
         self.forked = False
 
-    def run(self, fn, tensors):
-        if not self.enabled or PROFILE is not None or not tensors[0].is_cuda:
-            return fn()
-        if not self.forked:
+    def _note(self, main):
+        if not self.in_backward:
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(self.join)
             except RuntimeError:             # not inside a backward pass
-                return fn()
-            self.forked = True
-            self.main = torch.cuda.current_stream()
-            if self.stream is None or self.stream.device != self.main.device:
-                self.stream = torch.cuda.Stream(device=self.main.device)
-        self.stream.wait_stream(self.main)
+                return False
+            self.in_backward = True
+        if all(m != main for m in self.mains):
+            self.mains.append(main)
+        return True
+
+    def run(self, fn, tensors):
+        if not tensors[0].is_cuda:
+            return fn()
+        main = torch.cuda.current_stream()
+        if not self._note(main) or not self.enabled or PROFILE is not None:
+            return fn()
+        if self.stream is None or self.stream.device != main.device:
+            self.stream = torch.cuda.Stream(device=main.device)
+        self.stream.wait_stream(main)
         with torch.cuda.stream(self.stream):
             fn()
-        self.keep.append(tensors)            # the main stream's allocator must not recycle these before the join
+        self.keep.append(tensors)            # the forking stream's allocator must not recycle these before the join
+        self.forked = True
 
     def join(self):
+        cur = torch.cuda.current_stream()
         if self.forked:
-            self.main.wait_stream(self.stream)
-            self.keep.clear()
-            self.forked = False
+            for m in self.mains:
+                m.wait_stream(self.stream)
+            cur.wait_stream(self.stream)
+        for m in self.mains:
+            if m != cur:
+                cur.wait_stream(m)
+        self.keep.clear()
+        self.mains = []
+        self.in_backward = False
+        self.forked = False
 
 
 WGRAD_SIDE = _WgradSide()

@@ -1,0 +1,44 @@
+"""Fork / join of an independent sub-graph onto a second HIP stream.
+
+The pose network does not depend on the depth network until the loss (reference trainer.py:296-311): its seven small,
+latency-bound conv layers run beside the depth network's large kernels instead of between them.  autograd replays each
+backward node on the stream its forward ran on, so the backward pass inherits the same overlap without further code.
+"""
+import torch
+
+
+def _tensors(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _tensors(o)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            yield from _tensors(o)
+
+
+class Branch:
+    def __init__(self):
+        self.stream = None
+
+    def fork(self, fn, *args):
+        """Run fn(*args) on the branch stream, ordered after everything already queued on the current stream."""
+        cur = torch.cuda.current_stream()
+        if self.stream is None or self.stream.device != cur.device:
+            self.stream = torch.cuda.Stream(device=cur.device)
+        self.stream.wait_stream(cur)
+        for t in _tensors(args):
+            if t.is_cuda:
+                t.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            return fn(*args)
+
+    def join(self, out):
+        """Make the current stream wait for the branch; `out` (tensors made on the branch) becomes safe to use on it."""
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self.stream)
+        for t in _tensors(out):
+            if t.is_cuda:
+                t.record_stream(cur)
+        return out

@@ -63,6 +63,8 @@ class Trainer:
         mdist.broadcast_parameters(self.model_optimizer.arena())
 
         self.criterion = Losses()
+        from mcav.streams import Branch
+        self.pose_branch = Branch()
         self.loss = None
         self.valid_acc = 0
         if self.train_from_scratch:
@@ -159,12 +161,19 @@ class Trainer:
         ref_imgs = [img.to(dev, non_blocking=True) for img in samples['ref_imgs']]
         intrinsics = samples['intrinsics'].to(dev, non_blocking=True)
         gt = samples['groundtruth']
+        overlap = tgt.is_cuda and not semi_sup_pose
+        if overlap:        # the pose net is independent of the depth net until the loss: second HIP stream (mcav/streams.py)
+            from mcav import nn as mnn
+            mnn.refresh_packed_weights(tgt.device)      # both streams read the packed filters: refresh them before the fork
+            poses = self.pose_branch.fork(self.pose_model, tgt, ref_imgs)
         if hasattr(self.depth_model, "forward_pair"):
             disps = list(self.depth_model.forward_pair(tgt, ref_imgs[0]))          # == two separate passes (per-pass BN statistics)
         else:
             disps = [self.depth_model(image_t) for image_t in (tgt, ref_imgs[0])]  # two separate passes, as the reference
         if semi_sup_pose:
             poses = torch.cat((samples["oxts"][0].unsqueeze(1), samples["oxts"][1].unsqueeze(1)), 1).to(dev)
+        elif overlap:
+            poses = self.pose_branch.join(poses)
         else:
             poses = self.pose_model(tgt, ref_imgs)
         if warp_test:
