@@ -582,8 +582,17 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][T::LD];
     __shared__ int s_out[BM];
     __shared__ float s_stat[T::WAVES_M][2][BN];
-    __shared__ unsigned s_o1[TAB_TAPS][BM], s_o2[TAB_TAPS][BM];
-    __shared__ int s_rn[BM], s_ry[BM], s_rx[BM];
+    // LDS budget: with 32-deep 64x64 tiles everything below fits 40 KB, i.e. FOUR workgroups per CU.  The offset tables are dynamic
+    // shared memory sized by the launch (taps x BM x {1, 2} sources); the row coordinates are only needed while the tables are built
+    // and borrow the (not yet used) A panel, except in the REFL kind, whose border wavefronts re-read them inside the loop.
+    extern __shared__ unsigned s_dyn[];
+    unsigned* const s_o1 = s_dyn;
+    unsigned* const s_o2 = s_dyn + (p.g.C2 > 0 ? p.taps * BM : 0);
+    __shared__ int s_rows[REFL ? 3 * BM : 1];
+    int* const s_rn = REFL ? s_rows : reinterpret_cast<int*>(&As[0][0][0]);
+    int* const s_ry = s_rn + BM;
+    int* const s_rx = s_rn + 2 * BM;
+    static_assert(2 * BM * T::LD >= 3 * BM, "row coordinates fit the A panel");
     __shared__ int s_tl[TAB_TAPS + 1];
     __shared__ int s_nt;
 
@@ -638,8 +647,8 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
         ok = ok && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
         const int pix = (n * g.Hs + sy) * g.Ws + sx;
         const int pix1 = g.up1 ? ((n * (g.Hs >> 1) + (sy >> 1)) * (g.Ws >> 1) + (sx >> 1)) : pix;
-        s_o1[tp][r] = ok ? (unsigned)(pix1 * g.C1) * 4u : OOB;
-        s_o2[tp][r] = ok ? (unsigned)(pix * g.C2) * 4u : OOB;
+        s_o1[tp * BM + r] = ok ? (unsigned)(pix1 * g.C1) * 4u : OOB;
+        if (g.C2 > 0) s_o2[tp * BM + r] = ok ? (unsigned)(pix * g.C2) * 4u : OOB;
     }
     __syncthreads();
 
@@ -679,8 +688,8 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     auto refresh = [&]() {
 #pragma unroll
         for (int j = 0; j < T::AROWS; ++j) {
-            oa[j] = s_o1[tap][r0 + T::RPP * j] + (unsigned)c4 * 16u;      // OOB + 16 c4 is still out of range
-            ob[j] = s_o2[tap][r0 + T::RPP * j] + (unsigned)c4 * 16u;
+            oa[j] = s_o1[tap * BM + r0 + T::RPP * j] + (unsigned)c4 * 16u;      // OOB + 16 c4 is still out of range
+            ob[j] = s_o2[tap * BM + r0 + T::RPP * j] + (unsigned)c4 * 16u;      // (aliases s_o1 when there is no second source)
         }
     };
     refresh();
@@ -1487,8 +1496,9 @@ inline void launch_igemm(const IgemmParams& p, hipStream_t s) {
                      p.g.C1 + p.g.C2 == p.Kp && p.Kp % T::KD == 0 && (p.g.C2 == 0 || p.g.C1 % T::KD == 0) && !p.no_tab;
     // (tall tiles put rows of many image lines into one wavefront: most wavefronts would take the border path, so they keep the general kernel)
     const bool tab_refl = p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0 && p.g.C1 == p.Kp && p.Kp % T::KD == 0 && !p.no_tab && T::AROWS <= 2;
-    if (tab) igemm_tab_kernel<T, false><<<grid, 256, 0, s>>>(p);
-    else if (tab_refl) igemm_tab_kernel<T, true><<<grid, 256, 0, s>>>(p);
+    const size_t tab_bytes = sizeof(unsigned) * (size_t)p.taps * T::BM * (p.g.C2 > 0 ? 2 : 1);
+    if (tab) igemm_tab_kernel<T, false><<<grid, 256, tab_bytes, s>>>(p);
+    else if (tab_refl) igemm_tab_kernel<T, true><<<grid, 256, tab_bytes, s>>>(p);
     else if (fast_mode && c4ok) igemm_kernel<T, K_FAST><<<grid, 256, 0, s>>>(p);
     else if (p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0) igemm_kernel<T, K_REFLADJ><<<grid, 256, 0, s>>>(p);
     else igemm_kernel<T, K_GENERIC><<<grid, 256, 0, s>>>(p);

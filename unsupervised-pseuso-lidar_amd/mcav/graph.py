@@ -13,6 +13,8 @@ import torch
 class GraphedForwardBackward:
     def __init__(self, fwd_bwd, arena, example_inputs, warmup=3):
         """fwd_bwd(*inputs) -> tuple of tensors (e.g. the two losses); must zero the gradients itself."""
+        from . import streams
+        streams.SERIAL = True                      # single-stream issue from here on (see streams.py)
         self.arena = arena
         self.static_in = [x.clone() for x in example_inputs]
         side = torch.cuda.Stream()

@@ -350,8 +350,9 @@ class _WgradSide:
     def run(self, fn, tensors):
         if not tensors[0].is_cuda:
             return fn()
+        from . import streams
         main = torch.cuda.current_stream()
-        if not self._note(main) or not self.enabled or PROFILE is not None:
+        if not self._note(main) or not self.enabled or PROFILE is not None or streams.SERIAL:
             return fn()
         if self.stream is None or self.stream.device != main.device:
             self.stream = torch.cuda.Stream(device=main.device)

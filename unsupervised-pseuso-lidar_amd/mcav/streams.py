@@ -18,12 +18,21 @@ def _tensors(obj):
             yield from _tensors(o)
 
 
+# Set by mcav/graph.py: a captured hipGraph is replayed on ONE queue by this ROCm (its branches do not overlap), so under
+# capture everything is issued on the capturing stream -- same launches, no cross-stream edges in the graph.
+SERIAL = False
+
+
 class Branch:
     def __init__(self):
         self.stream = None
+        self.inline = False
 
     def fork(self, fn, *args):
         """Run fn(*args) on the branch stream, ordered after everything already queued on the current stream."""
+        self.inline = SERIAL or not any(t.is_cuda for t in _tensors(args))
+        if self.inline:
+            return fn(*args)
         cur = torch.cuda.current_stream()
         if self.stream is None or self.stream.device != cur.device:
             self.stream = torch.cuda.Stream(device=cur.device)
@@ -36,6 +45,8 @@ class Branch:
 
     def join(self, out):
         """Make the current stream wait for the branch; `out` (tensors made on the branch) becomes safe to use on it."""
+        if self.inline:
+            return out
         cur = torch.cuda.current_stream()
         cur.wait_stream(self.stream)
         for t in _tensors(out):
