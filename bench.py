@@ -190,6 +190,8 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         # instrumented step(s): every conv launch bracketed by events on the launch stream
+        from mcav import streams
+        serial_before, streams.SERIAL = streams.SERIAL, True      # one stream: a launch's events bracket that kernel alone
         N.PROFILE = []
         N.PROFILE_LOSS = []
         N.PROFILE_TAGS = [] if args.layer_report else None
@@ -197,6 +199,7 @@ def main():
             eager_step()                      # instrumented launches must be issued eagerly (events are not graph nodes)
         torch.cuda.synchronize()
         recs, N.PROFILE = N.PROFILE, None
+        streams.SERIAL = serial_before
         if args.layer_report:
             tags, N.PROFILE_TAGS = N.PROFILE_TAGS, None
             n1 = len(recs) // 3

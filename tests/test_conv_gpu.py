@@ -54,6 +54,10 @@ CASES = [
     (2, 12, 20, 128, 128, 3, 1, 1, 1, 2, 9),    # 32-deep K-tiles, 128x128, reflection pad
     (1, 10, 18, 64, 128, 3, 2, 1, 0, 0, 10),    # 32-deep K-tiles, 64x64, stride 2 (and its parity-class adjoint)
     (2, 6, 10, 96, 32, 3, 1, 1, 1, 2, 10),      # Cin = 96 with 32-deep K-tiles
+    (2, 9, 35, 16, 32, 3, 1, 1, 1, 2, 0),       # halo-tile kernel: 16 -> 32, ragged tiles in both directions
+    (1, 17, 66, 16, 16, 3, 1, 1, 0, 1, 0),      # halo-tile kernel with zero padding
+    (2, 12, 20, 16, 16, 3, 1, 1, 1, 2, 0x200),  # the same shapes through the general kernels (bit 9)
+    (2, 6, 10, 32, 16, 3, 1, 1, 1, 2, 0x200),
 ]
 
 
@@ -80,7 +84,7 @@ def test_conv_fwd_dgrad_wgrad(case):
     dyd = nhwc(dy)
     dx = N.conv_dgrad(spec, dyd, (H, W), tile=tile)
     assert rel_err(nchw(dx, Cin), x.grad) < 2e-5
-    wt = tile if tile in (1, 2, 3, 4, 6, 7) else 0
+    wt = tile if tile in (1, 2, 3, 4, 6, 7, 0x100) else 0
     N.conv_wgrad(spec, xin, dyd, tile=wt)
     assert rel_err(wp.grad, w.grad) < 5e-5
     assert rel_err(bp.grad, b.grad) < 5e-5
@@ -246,3 +250,28 @@ def test_one_channel_head_stencil(shape):
     assert rel_err(wp.grad, w.grad) < 5e-5 and rel_err(bp.grad, b.grad) < 5e-5
     N.conv3x3r_c1_bwd(spec, xd, nhwc(ddisp), got, N.ACT_SIGMOID, N.ACT_ELU)       # accumulates into .grad; no addend
     assert rel_err(wp.grad, 2 * w.grad) < 5e-5
+
+
+def test_halo_kernel_fused_upsample():
+    """Decoder conv (0,1): 3x3 reflect conv on the nearest-upsampled 16-channel map, no skip tensor (halo-tile kernels):
+    forward, and the data gradient back through the upsample (2x2 sum) and the producer's ELU, plus an addend."""
+    from mcav import nn as N
+    g = torch.Generator().manual_seed(11)
+    for (B, h, w_, C, Cout) in [(2, 7, 19, 16, 16), (1, 1, 1, 16, 32), (2, 4, 16, 32, 16), (1, 5, 40, 32, 32)]:
+        pre_a = torch.randn(B, C, h, w_, generator=g).requires_grad_()
+        a = F.elu(pre_a)
+        wt = torch.randn(Cout, C, 3, 3, generator=g) * 0.1
+        bs = 0.1 * torch.randn(Cout, generator=g)
+        pre = F.conv2d(F.pad(F.interpolate(a, scale_factor=2, mode="nearest"), (1, 1, 1, 1), mode="reflect"), wt, bs)
+        want = F.elu(pre)
+        dy = torch.randn(pre.shape, generator=g)
+        addend = torch.randn(B, C, h, w_, generator=g)
+        pre.backward(dy)
+        spec = N.ConvSpec(torch.nn.Parameter(wt.to(DEV)), torch.nn.Parameter(bs.to(DEV)), 1, 1, N.PAD_REFLECT)
+        ad = nhwc(a.detach())
+        for tile in (0, 0x200):                                                   # halo-tile kernels, then the general ones
+            got = N.conv_fwd(spec, ad, None, up1=True, act=N.ACT_ELU, tile=tile)
+            assert rel_err(nchw(got), want) < 2e-5
+            da = N.conv_dgrad(spec, nhwc(dy), (2 * h, 2 * w_), n_begin=0, n_count=C, dact_aux=ad, dact=N.ACT_ELU, addend=nhwc(addend),
+                              pool=True, tile=tile)
+            assert rel_err(nchw(da), pre_a.grad + addend) < 2e-5

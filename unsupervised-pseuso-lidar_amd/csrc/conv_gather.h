@@ -95,4 +95,79 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// ------------------------------------------------------------------------------------------------ shared by the conv kernels
+struct IgemmParams {
+    GatherSrc g;
+    const float* w;
+    int kh, kw, Kp, Kstride, taps;
+    float* y;
+    int Hd, Wd, Cd, n_begin, n_count, y_choff;
+    const float* bias;
+    int act;
+    const float* dact_aux;
+    int dact;
+    const float* addend;
+    int pool;
+    float* stats;
+    int M;           // rows of the GEMM (incl. class / group padding)
+    int Mc, McP;     // ADJ_STRIDE2: pixels per parity class and its BM-padded size; groups > 1: rows per group and padded size
+    int groups;
+    int mtiles, ntiles;
+    int no_tab;      // desc.tile bit 8: force the general kernel (A/B timing and parity of both paths)
+};
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == MCAV_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == MCAV_ACT_ELU) return v > 0.f ? v : expm1f(v);
+    if (act == MCAV_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+// derivative of the activation expressed through its OUTPUT y
+__device__ __forceinline__ float act_bwd(float y, int act) {
+    if (act == MCAV_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == MCAV_ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
+    if (act == MCAV_ACT_SIGMOID) return y * (1.f - y);
+    return 1.f;
+}
+
+// Raw buffer loads: an offset at or beyond num_records reads as zero in hardware, so padding / out-of-image rows need
+// neither a branch nor a select after the load (either would force an s_waitcnt right behind it).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;      // "reads as zero": every tensor here is < 2 GiB (checked on the host)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
+}
+
+// Hand-counted variant for the K_FAST main loop: the load is invisible to the compiler's s_waitcnt bookkeeping (which, across
+// the loop back-edge, would drain the youngest loads too), so tile t+2 can stay in flight while tile t+1 is written to LDS.
+// The destination registers must not be touched until the matching vm_wait<N>() below.
+__device__ __forceinline__ u32x4 make_rsrc_words(const void* ptr, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    u32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+
+__device__ __forceinline__ void asm_buf_load4(f32x4& v, u32x4 rsrc, unsigned byte_off) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(byte_off), "s"(rsrc) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
+__device__ __forceinline__ f32x4 buf_load4s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int sbyte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, sbyte_off, 0));
+}
+
 }  // namespace mcav
