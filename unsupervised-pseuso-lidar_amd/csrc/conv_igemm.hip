@@ -1472,9 +1472,15 @@ struct WgradPlan {
     WgradParams p;
     int tile;
     bool use_tab;
+    bool use_halo;
     size_t slab_bytes, pre_bytes;
     int ci_t, groups, per_group;
 };
+
+}  // namespace mcav
+int mcav_halo_wgrad_splits(const mcav_wgrad_desc* d);
+void mcav_halo_wgrad_launch(const mcav_wgrad_desc* d, float* slab, int slabN, int splits, hipStream_t s);
+namespace mcav {
 
 inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     if (!d || !d->x1 || !d->dy || !d->dw_oihw) return false;
@@ -1533,6 +1539,9 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
         }
     }
     p.splits = (p.Mpix + p.pix_per_split - 1) / p.pix_per_split;
+    const int halo_splits = mcav_halo_wgrad_splits(d);           // narrow high-resolution layers: conv_halo.hip writes the slab partials
+    pl.use_halo = halo_splits > 0;
+    if (pl.use_halo) { p.splits = halo_splits; pl.use_tab = false; }
     p.want_bias = d->dbias != nullptr;
     pl.slab_bytes = align_up(sizeof(float) * (size_t)p.splits * (p.Ktot + 1) * p.slabN, 256);
     pl.groups = p.splits > 8 ? 8 : 0;                            // two-level reduction above 8 splits
@@ -1573,7 +1582,8 @@ MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t wor
     if (workspace_bytes < pl.slab_bytes + pl.pre_bytes) return MCAV_E_WORKSPACE;
     hipStream_t s = as_stream(stream);
     pl.p.slab = reinterpret_cast<float*>(workspace);
-    switch (pl.tile) {
+    if (pl.use_halo) mcav_halo_wgrad_launch(d, pl.p.slab, pl.p.slabN, pl.p.splits, s);
+    else switch (pl.tile) {
         case 1: launch_wgrad<Tile128x64>(pl.p, pl.use_tab, s); break;
         case 2: launch_wgrad<Tile64x64>(pl.p, pl.use_tab, s); break;
         case 3: launch_wgrad<Tile256x32>(pl.p, pl.use_tab, s); break;
