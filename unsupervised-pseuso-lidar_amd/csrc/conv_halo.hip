@@ -28,6 +28,7 @@ struct HaloParams {
     int act;
     float* y;
     int Cd, n_count;      // output row stride and real channels
+    int co0;              // first output channel of this launch (wide outputs are produced in blocks of 32 channels)
     const float* dact_aux;
     int dact;
     const float* addend;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams p) {
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc)
-                wv[f][t][kc] = *reinterpret_cast<const f32x4*>(p.w + ((size_t)(p.n_begin + f * 16 + nn) * 9 + t) * C + kc * 16 + g * 4);
+                wv[f][t][kc] = *reinterpret_cast<const f32x4*>(p.w + ((size_t)(p.n_begin + p.co0 + f * 16 + nn) * 9 + t) * C + kc * 16 + g * 4);
 
     // ---- halo: one pass, all loads in flight together
     const int Hs = p.up ? p.H >> 1 : p.H, Ws = p.up ? p.W >> 1 : p.W;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams p) {
     // ---- epilogue.  C/D layout 16x16: column = lane & 15 (output channel), rows 4 (lane >> 4) + e (pixel column within the fragment)
 #pragma unroll
     for (int h = 0; h < NF; ++h) {
-        const int co = h * 16 + nn;
+        const int co = p.co0 + h * 16 + nn;
         const bool cok = co < p.n_count;
         const float bv = (p.bias && cok) ? p.bias[co] : 0.f;
         if (ADJ && p.pool) {
@@ -384,7 +385,7 @@ using namespace mcav;
 bool mcav_try_halo(const mcav_igemm_desc* d, hipStream_t s) {
     if (d->kh != 3 || d->kw != 3 || d->stride != 1) return false;
     if (d->C2 != 0 || d->x2 || (d->C1 != 16 && d->C1 != 32) || d->Kp != d->C1) return false;
-    if (d->n_count > 32 || d->stats || d->groups > 1 || d->y_choff != 0) return false;
+    if (d->n_count > 64 || d->stats || d->groups > 1 || d->y_choff != 0) return false;
     if (d->Hd != d->Hs || d->Wd != d->Ws || d->Hs < 2 || d->Ws < 2) return false;
     if ((d->tile >> 9) & 1) return false;                      // desc.tile bit 9: force the general kernels (A/B timing, parity of both)
     const bool adj = d->mode == MCAV_G_ADJ_REFLECT;
@@ -396,6 +397,7 @@ bool mcav_try_halo(const mcav_igemm_desc* d, hipStream_t s) {
         if (d->n_begin != 0 || d->pool || d->dact_aux || d->addend) return false;
     }
     const int nf = d->n_count > 16 ? 2 : 1;
+    if (d->n_begin + (d->n_count > 32 ? 64 : nf * 16) > d->Np) return false;      // every filter row a launch touches exists in the packed copy
     HaloParams p;
     p.x = d->x1; p.B = d->B; p.H = d->Hs; p.W = d->Ws; p.up = d->up1; p.pad_mode = d->pad_mode;
     p.w = d->w; p.n_begin = d->n_begin; p.bias = d->bias; p.act = d->act; p.y = d->y; p.Cd = d->Cd; p.n_count = d->n_count;
@@ -404,10 +406,12 @@ bool mcav_try_halo(const mcav_igemm_desc* d, hipStream_t s) {
     const int grid = p.B * p.tiles_x * p.tiles_y;
 #define HALO_LAUNCH(CC, NN) \
     do { if (adj) conv3x3_halo_kernel<CC, NN, true><<<grid, 256, 0, s>>>(p); else conv3x3_halo_kernel<CC, NN, false><<<grid, 256, 0, s>>>(p); } while (0)
-    if (d->C1 == 16 && nf == 1) HALO_LAUNCH(16, 1);
-    else if (d->C1 == 16) HALO_LAUNCH(16, 2);
-    else if (nf == 1) HALO_LAUNCH(32, 1);
-    else HALO_LAUNCH(32, 2);
+    for (p.co0 = 0; p.co0 < d->n_count; p.co0 += 32) {      // more than 32 output channels: one launch per block of 32 (the halo is small)
+        if (d->C1 == 16 && nf == 1) HALO_LAUNCH(16, 1);
+        else if (d->C1 == 16) HALO_LAUNCH(16, 2);
+        else if (nf == 1) HALO_LAUNCH(32, 1);
+        else HALO_LAUNCH(32, 2);
+    }
 #undef HALO_LAUNCH
     return true;
 }
