@@ -107,7 +107,9 @@ int mcav_pack_weights_multi(const void* items_dev, int nitems, int nblocks, void
  * stencil kernels instead of an N = 1 implicit GEMM.  x NHWC [B,H,W,C], C in {16, 32, 64, 128}; w_oihw [1][C][3][3].
  *   fwd: y[B,H,W] = act(conv(x) + bias[0]).
  *   bwd: with dpre = dy * act'(y):  dx = adjoint(dpre) * x_act'(x) + addend   (x_act = the activation that PRODUCED x, its
- *        derivative taken through x; addend may be NULL),  dw_oihw (+)= wgrad,  dbias[0] (+)= sum(dpre)  -- one pass over x. */
+ *        derivative taken through x; addend may be NULL),  dw_oihw (+)= wgrad,  dbias[0] (+)= sum(dpre)  -- one pass over x.
+ *        y = NULL with act = MCAV_ACT_NONE: dy already is dpre (every dpre value is gathered by 9 neighbours: pre-multiplying
+ *        it once with mcav_act_bwd halves the gathers). */
 int mcav_conv3x3r_c1_fwd(const float* x, int B, int H, int W, int C, const float* w_oihw, const float* bias, int act, float* y,
                          void* stream);
 size_t mcav_conv3x3r_c1_bwd_workspace_bytes(int C);

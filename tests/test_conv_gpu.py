@@ -116,11 +116,13 @@ def test_conv_stats_and_epilogues():
     assert rel_err(nchw(got), want_dx) < 2e-5
 
 
-def test_decoder_level_fused_upsample_concat():
-    """conv(cat(up2(a), skip)) with reflection padding: forward, wgrad, and the split/pooled dgrad."""
+@pytest.mark.parametrize("dims", [(2, 5, 7), (1, 128, 208)])
+def test_decoder_level_fused_upsample_concat(dims):
+    """conv(cat(up2(a), skip)) with reflection padding: forward, wgrad, and the split/pooled dgrad.
+    The large case has 725 pixels per wgrad split x 3 taps x 2 sources: the offset table is consumed in chunks."""
     from mcav import nn as N
     g = torch.Generator().manual_seed(4)
-    B, h, w_, C1, C2, Cout = 2, 5, 7, 32, 64, 32
+    (B, h, w_), C1, C2, Cout = dims, 32, 64, 32
     a = torch.randn(B, C1, h, w_, generator=g).requires_grad_()
     skip = torch.randn(B, C2, 2 * h, 2 * w_, generator=g).requires_grad_()
     wt = (torch.randn(Cout, C1 + C2, 3, 3, generator=g) * 0.05).requires_grad_()
@@ -222,7 +224,8 @@ def test_maxpool_adam_misc():
     assert rel_err(out, 0.06 * t.mean((1, 2))) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 12, 16), (1, 2, 2, 16), (2, 3, 5, 32), (1, 37, 70, 16), (1, 6, 9, 64), (1, 4, 4, 128)])
+@pytest.mark.parametrize("shape", [(2, 8, 12, 16), (1, 2, 2, 16), (2, 3, 5, 32), (1, 37, 70, 16), (1, 6, 9, 64), (1, 4, 4, 128),
+                                   (1, 256, 256, 16)])      # the last one is large enough for the pre-multiplied-gradient path
 def test_one_channel_head_stencil(shape):
     """The disparity head (3x3 reflect conv to ONE channel + sigmoid): stencil forward and the fused one-pass backward
     (d input through ELU' + addend, weight and bias gradients) against torch, including the reflected border lines."""

@@ -385,7 +385,7 @@ using namespace mcav;
 bool mcav_try_halo(const mcav_igemm_desc* d, hipStream_t s) {
     if (d->kh != 3 || d->kw != 3 || d->stride != 1) return false;
     if (d->C2 != 0 || d->x2 || (d->C1 != 16 && d->C1 != 32) || d->Kp != d->C1) return false;
-    if (d->n_count > 64 || d->stats || d->groups > 1 || d->y_choff != 0) return false;
+    if (d->n_count > 32 || d->stats || d->groups > 1 || d->y_choff != 0) return false;      // wider outputs: the table-driven kernel is faster
     if (d->Hd != d->Hs || d->Wd != d->Ws || d->Hs < 2 || d->Ws < 2) return false;
     if ((d->tile >> 9) & 1) return false;                      // desc.tile bit 9: force the general kernels (A/B timing, parity of both)
     const bool adj = d->mode == MCAV_G_ADJ_REFLECT;
@@ -396,8 +396,9 @@ bool mcav_try_halo(const mcav_igemm_desc* d, hipStream_t s) {
         if (d->mode != MCAV_G_DIRECT || d->sign != 1 || d->offset != -1) return false;
         if (d->n_begin != 0 || d->pool || d->dact_aux || d->addend) return false;
     }
-    const int nf = d->n_count > 16 ? 2 : 1;
-    if (d->n_begin + (d->n_count > 32 ? 64 : nf * 16) > d->Np) return false;      // every filter row a launch touches exists in the packed copy
+    // 32 input channels x 32 output channels would hold 144 filter registers per lane (one wavefront per SIMD): two launches of 16
+    const int nf = (d->n_count > 16 && d->C1 == 16) ? 2 : 1;
+    if (d->n_begin + (d->n_count + 15) / 16 * 16 > d->Np) return false;            // every filter row a launch touches exists in the packed copy
     HaloParams p;
     p.x = d->x1; p.B = d->B; p.H = d->Hs; p.W = d->Ws; p.up = d->up1; p.pad_mode = d->pad_mode;
     p.w = d->w; p.n_begin = d->n_begin; p.bias = d->bias; p.act = d->act; p.y = d->y; p.Cd = d->Cd; p.n_count = d->n_count;
@@ -406,11 +407,10 @@ bool mcav_try_halo(const mcav_igemm_desc* d, hipStream_t s) {
     const int grid = p.B * p.tiles_x * p.tiles_y;
 #define HALO_LAUNCH(CC, NN) \
     do { if (adj) conv3x3_halo_kernel<CC, NN, true><<<grid, 256, 0, s>>>(p); else conv3x3_halo_kernel<CC, NN, false><<<grid, 256, 0, s>>>(p); } while (0)
-    for (p.co0 = 0; p.co0 < d->n_count; p.co0 += 32) {      // more than 32 output channels: one launch per block of 32 (the halo is small)
+    for (p.co0 = 0; p.co0 < d->n_count; p.co0 += 16 * nf) {
         if (d->C1 == 16 && nf == 1) HALO_LAUNCH(16, 1);
         else if (d->C1 == 16) HALO_LAUNCH(16, 2);
-        else if (nf == 1) HALO_LAUNCH(32, 1);
-        else HALO_LAUNCH(32, 2);
+        else HALO_LAUNCH(32, 1);
     }
 #undef HALO_LAUNCH
     return true;

@@ -764,6 +764,7 @@ struct WgradParams {
     float* slab;                   // [splits][Ktot + 1][slabN]; row Ktot holds the per-split column sums of dy (bias gradient)
     int slabN;                     // row stride of the slab (Cout rounded up to 16)
     int want_bias;
+    int tab_cht_log2;              // wgrad_tab_kernel: log2 of the tiles per table chunk (>= 20: the whole split is one chunk)
 };
 
 constexpr int KP = 32;   // pixels per K-tile of the wgrad GEMM
@@ -1013,12 +1014,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 
 // Table-driven weight-gradient kernel: same GEMM, tiling, LDS panels and epilogue as wgrad_kernel, with the addressing taken
 // out of the K loop (the GEMM's reduction runs over PIXELS here, so every K-tile needs fresh source addresses):
-//   * once per workgroup, the source byte offset of every (pixel of this split, filter tap touched by this row tile) goes to
-//     an LDS table -- padding, reflection, stride, upsampling are resolved there, invalid taps hold an out-of-range offset;
+//   * the source byte offset of every (pixel, filter tap touched by this row tile, source tensor) lives in an LDS table --
+//     padding, reflection, stride, upsampling are resolved there, invalid taps hold an out-of-range offset.  A split whose
+//     pixels fit has the whole table built once; longer splits use it as two half-buffers of CHT tiles each, the next
+//     chunk being computed (one pixel per thread) while the current one is consumed, fenced by the per-tile barriers;
 //   * per A load the loop does one ds_read_b32 (prefetched a tile ahead) and one v_add (the lane's channel offset);
 //   * dy rows advance linearly: their loads use the instruction's SCALAR offset, and the buffer resource ends at this
 //     split's last pixel, so the ragged last tile needs no masking.
-// The host sizes the splits so that the table fits (WG_TABCAP entries); otherwise the general kernel runs.
 constexpr int WG_TABCAP = 4096;
 
 template <class T>
@@ -1045,34 +1047,43 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
     const int pix_begin = split * p.pix_per_split;
     const int pix_end = min(p.Mpix, pix_begin + p.pix_per_split);
     const int T_total = pix_end > pix_begin ? (pix_end - pix_begin + KP - 1) / KP : 0;
-    const int npx = T_total * KP;                         // table entries per tap (rows past pix_end are out of range)
     const int tap_lo = m0 / p.Kp;
     const int tap_hi = min(p.taps - 1, (m0 + BM - 1) / p.Kp);
     const int NT = tap_hi - tap_lo + 1;
     const bool two = g.C2 > 0;                            // second table: offsets into x2 (x1 may be the upsampled source)
+    // chunking: CHT = 2^cht tiles per half-buffer; a split that fits is one chunk (cht large, second half never used)
+    const int cht = p.tab_cht_log2;
+    const int npc = min(T_total, 1 << min(cht, 20)) * KP;   // pixels per chunk
+    const int half = NT * (two ? 2 : 1) * npc;            // entries per half-buffer
 
-    // ---- table: [source][tap - tap_lo][pixel - pix_begin]
-    for (int pl = tid; pl < npx; pl += 256) {
-        const int m = pix_begin + pl;
-        const bool live = m < pix_end;
-        const int n = m / (p.Hd * p.Wd);
-        const int r = m - n * (p.Hd * p.Wd);
-        const int dy = r / p.Wd, dx = r - dy * p.Wd;
-        for (int tl = 0; tl < NT; ++tl) {
-            const int tap = tap_lo + tl;
-            const int ky = tap / p.kw, kx = tap - ky * p.kw;
-            int sy = dy * g.stride + ky + g.offset, sx = dx * g.stride + kx + g.offset;      // sign = +1 (forward gather)
-            if (g.pad_mode == MCAV_PAD_REFLECT) {
-                sy = reflect_idx(sy, g.Hs);
-                sx = reflect_idx(sx, g.Ws);
+    // chunk c -> half-buffer c & 1: [source][tap - tap_lo][pixel within the chunk]
+    auto build_chunk = [&](int c) {
+        unsigned* tb = s_tab + (c & 1) * half;
+        for (int pl = tid; pl < npc; pl += 256) {
+            const int m = pix_begin + c * npc + pl;
+            const bool live = m < pix_end;
+            const int n = m / (p.Hd * p.Wd);
+            const int r = m - n * (p.Hd * p.Wd);
+            const int dy = r / p.Wd, dx = r - dy * p.Wd;
+            for (int tl = 0; tl < NT; ++tl) {
+                const int tap = tap_lo + tl;
+                const int ky = tap / p.kw, kx = tap - ky * p.kw;
+                int sy = dy * g.stride + ky + g.offset, sx = dx * g.stride + kx + g.offset;      // sign = +1 (forward gather)
+                if (g.pad_mode == MCAV_PAD_REFLECT) {
+                    sy = reflect_idx(sy, g.Hs);
+                    sx = reflect_idx(sx, g.Ws);
+                }
+                const bool ok = live && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
+                const int pix = (n * g.Hs + sy) * g.Ws + sx;
+                const int pix1 = g.up1 ? ((n * (g.Hs >> 1) + (sy >> 1)) * (g.Ws >> 1) + (sx >> 1)) : pix;
+                tb[tl * npc + pl] = ok ? (unsigned)(pix1 * g.C1) * 4u : OOB;
+                if (two) tb[(NT + tl) * npc + pl] = ok ? (unsigned)(pix * g.C2) * 4u : OOB;
             }
-            const bool ok = live && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
-            const int pix = (n * g.Hs + sy) * g.Ws + sx;
-            const int pix1 = g.up1 ? ((n * (g.Hs >> 1) + (sy >> 1)) * (g.Ws >> 1) + (sx >> 1)) : pix;
-            s_tab[tl * npx + pl] = ok ? (unsigned)(pix1 * g.C1) * 4u : OOB;
-            if (two) s_tab[(NT + tl) * npx + pl] = ok ? (unsigned)(pix * g.C2) * 4u : OOB;
         }
-    }
+    };
+    const int nchunks = npc > 0 ? (T_total * KP + npc - 1) / npc : 0;
+    if (nchunks > 0) build_chunk(0);
+    if (nchunks > 1) build_chunk(1);
 
     // ---- this thread's A column: filter tap and channel; a wavefront's columns lie in one source
     int tl_own = 0, ac = 0;
@@ -1093,7 +1104,7 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
     // Lanes on K-padding channels or on rows past Ktot add the out-of-range bit: they read zero (or, under an out-of-image tap whose
     // table entry carries the same bit, whatever sits at the wrapped offset) into GEMM rows that nothing consumes.
     const unsigned chan = a_ok ? (unsigned)acc_ * 4u : OOB;
-    const unsigned* trow = &s_tab[((use2 ? NT : 0) + (a_ok ? tl_own : 0)) * npx + apix];
+    const int trow = ((use2 ? NT : 0) + (a_ok ? tl_own : 0)) * npc + apix;      // this lane's row inside a half-buffer
     unsigned boff[BPASS];
 #pragma unroll
     for (int j = 0; j < BPASS; ++j) {
@@ -1108,8 +1119,10 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
     unsigned toff[APASS];                                 // table values of the next tile to issue
     int u = 0;                                            // the issue pointer
     auto fetch = [&]() {
+        const int uc = u >> cht, ul = u - (uc << cht);    // chunk of tile u and its position inside it
+        const unsigned* tr = s_tab + (uc & 1) * half + trow + ul * KP;
 #pragma unroll
-        for (int j = 0; j < APASS; ++j) toff[j] = trow[u * KP + j * APIX];
+        for (int j = 0; j < APASS; ++j) toff[j] = tr[j * APIX];
     };
     auto issue = [&](f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
 #pragma unroll
@@ -1196,11 +1209,18 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
         if (T_total > 1) issue(ra, rb);
     }
     __syncthreads();
+    // Chunk c + 1 is computed when the compute pointer enters chunk c: its half-buffer held chunk c - 1, whose last entry was
+    // fetched three steps ago, and its first entry is fetched no earlier than the next step (CHT >= 4) -- barriers on both sides.
+    auto maybe_build = [&]() {
+        if (t > 0 && (t & ((1 << cht) - 1)) == 0 && (t >> cht) + 1 < nchunks) build_chunk((t >> cht) + 1);
+    };
     for (; t + 3 < T_total; t += 2) {
+        maybe_build();
         step(B0{}, B1{});
         step(B1{}, B0{});
     }
     for (; t < T_total; ++t) {
+        maybe_build();
         if (t & 1) {
             if (t + 1 < T_total) { store(ra, rb, B0{}); if (t + 2 < T_total) issue(ra, rb); }
             compute(B1{});
@@ -1525,17 +1545,21 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     const int wave_ch = BM / 4;
     const bool fast = d->mode == MCAV_G_DIRECT && (d->C1 & 3) == 0 && (d->C2 & 3) == 0 && (d->C2 == 0 || d->C1 % wave_ch == 0) &&
                       (p.CoutLoad & 3) == 0 && (d->Cdy & 3) == 0 && (d->dy_choff & 3) == 0 && !((d->tile >> 8) & 1);
+    p.tab_cht_log2 = 20;
     if (fast) {
         int ntmax = 1;
         for (int mt = 0; mt < p.mtiles; ++mt) {
             const int lo = mt * BM / d->Kp, hi = (mt * BM + BM - 1) / d->Kp < p.taps - 1 ? (mt * BM + BM - 1) / d->Kp : p.taps - 1;
             if (hi - lo + 1 > ntmax) ntmax = hi - lo + 1;
         }
-        const int cap_pix = WG_TABCAP / (ntmax * (d->C2 > 0 ? 2 : 1)) / KP * KP;
-        if (cap_pix >= 8 * KP) {
-            int pps = p.pix_per_split < cap_pix ? p.pix_per_split : cap_pix;
-            const int need = (p.Mpix + pps - 1) / pps;
-            if (need <= 512) { p.pix_per_split = pps; pl.use_tab = true; }
+        const int epp = ntmax * (d->C2 > 0 ? 2 : 1);                      // table entries per pixel
+        if ((long)p.pix_per_split * epp <= WG_TABCAP) {
+            pl.use_tab = true;                                            // one chunk
+        } else if (epp <= 16) {
+            int lg = 2;                                                   // two half-buffers of 2^lg tiles: 2^lg * KP * epp <= WG_TABCAP / 2
+            while ((2 << lg) * KP * epp <= WG_TABCAP / 2) ++lg;
+            p.tab_cht_log2 = lg;
+            pl.use_tab = true;
         }
     }
     p.splits = (p.Mpix + p.pix_per_split - 1) / p.pix_per_split;

@@ -85,9 +85,9 @@ __global__ __launch_bounds__(256) void conv3x3r_c1_bwd_kernel(const float* __res
     }
     float db = 0.f;
     const long npix = (long)B * H * W;
-    auto dpre_at = [&](int n, int yy, int xx) -> float {
+    auto dpre_at = [&](int n, int yy, int xx) -> float {      // yout == NULL: dy already is the pre-activation gradient
         const size_t o = (size_t)(n * H + yy) * W + xx;
-        return dy[o] * nc_act_bwd(yout[o], act);
+        return yout ? dy[o] * nc_act_bwd(yout[o], act) : dy[o];
     };
     for (long p = (long)blockIdx.x * PPB + threadIdx.x / LPP; p < npix; p += (long)gridDim.x * PPB) {
         const int n = (int)(p / ((long)H * W));
@@ -211,7 +211,8 @@ MCAV_EXPORT size_t mcav_conv3x3r_c1_bwd_workspace_bytes(int C) {
 MCAV_EXPORT int mcav_conv3x3r_c1_bwd(const float* x, int B, int H, int W, int C, const float* w_oihw, const float* dy, const float* y, int act,
                                      int x_act, const float* addend, float* dx, float* dw_oihw, float* dbias, int accumulate, void* workspace,
                                      size_t workspace_bytes, void* stream) {
-    if (!x || !w_oihw || !dy || !y || !dx || !dw_oihw || !workspace || B <= 0 || H < 2 || W < 2 || !nc_ok(C)) return MCAV_E_INVALID;
+    if (!x || !w_oihw || !dy || !dx || !dw_oihw || !workspace || B <= 0 || H < 2 || W < 2 || !nc_ok(C)) return MCAV_E_INVALID;
+    if (!y && act != MCAV_ACT_NONE) return MCAV_E_INVALID;
     if (workspace_bytes < mcav_conv3x3r_c1_bwd_workspace_bytes(C)) return MCAV_E_WORKSPACE;
     const long npix = (long)B * H * W;
     if (npix >= (1L << 31)) return MCAV_E_INVALID;

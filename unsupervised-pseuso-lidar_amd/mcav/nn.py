@@ -538,6 +538,8 @@ def conv3x3r_c1_bwd(spec, x, dy, y, act, x_act, addend=None):
     """Fused backward of the head: -> dx = adjoint(dy * act'(y)) * x_act'(x) + addend; accumulates weight / bias gradients."""
     B, H, W, C = x.shape
     h = L.lib()
+    if act != ACT_NONE and B * H * W >= (1 << 16):      # large maps: one elementwise pass for dy * act'(y), then half the gathers
+        dy, y, act = act_bwd(dy, y, act), None, ACT_NONE
     ws = L.workspace(h.mcav_conv3x3r_c1_bwd_workspace_bytes(C), x.device, "narrow")
     dx = torch.empty_like(x)
     gw = grad_buffer(spec.weight)
