@@ -55,7 +55,9 @@ def main():
         if a.startswith("--tiles"):
             tiles = [int(t, 0) for t in a.split("=")[1].split(",")]
     dev = "cuda"
+    batch = int(os.environ.get("CONV_BENCH_BATCH", "0"))      # 24 = the stacked tgt/ref0 passes of the step
     for (B, H, W, Cin, Cout, k, s, p, pm) in SHAPES:
+        B = batch or B
         w = torch.nn.Parameter(torch.randn(Cout, Cin, k, k, device=dev) * 0.05)
         b = torch.nn.Parameter(torch.zeros(Cout, device=dev))
         spec = N.ConvSpec(w, b, s, p, pm)

@@ -1258,12 +1258,22 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
 
 // First reduction level when there are many pixel splits: dst[g][e] = sum of the splits of group g (fixed order).
 __global__ __launch_bounds__(256) void wgrad_presum_kernel(const float* slab, int splits, size_t elems, int per_group, float* dst) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= elems) return;
+    // elems is a multiple of 16 (slabN is): 16-byte accesses, four independent partial sums keep several loads in flight
+    const size_t e4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e4 * 4 >= elems) return;
     const int k0 = blockIdx.y * per_group, k1 = min(splits, k0 + per_group);
-    float s = 0.f;
-    for (int k = k0; k < k1; ++k) s += slab[(size_t)k * elems + e];
-    dst[(size_t)blockIdx.y * elems + e] = s;
+    const f32x4* src = reinterpret_cast<const f32x4*>(slab) + e4;
+    const size_t stride4 = elems / 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int k = k0;
+    for (; k + 3 < k1; k += 4) {
+        s0 += src[(size_t)k * stride4];
+        s1 += src[(size_t)(k + 1) * stride4];
+        s2 += src[(size_t)(k + 2) * stride4];
+        s3 += src[(size_t)(k + 3) * stride4];
+    }
+    for (; k < k1; ++k) s0 += src[(size_t)k * stride4];
+    reinterpret_cast<f32x4*>(dst)[(size_t)blockIdx.y * stride4 + e4] = (s0 + s1) + (s2 + s3);
 }
 
 // slab [splits][Ktot + 1][slabN] -> OIHW gradient (+ bias gradient), fixed summation order, optional accumulate.
@@ -1623,7 +1633,7 @@ MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t wor
     if (pl.groups) {
         float* pre = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pl.slab_bytes);
         const size_t elems = (size_t)(pl.p.Ktot + 1) * pl.p.slabN;
-        wgrad_presum_kernel<<<dim3((unsigned)((elems + 255) / 256), pl.groups), 256, 0, s>>>(pl.p.slab, pl.p.splits, elems, pl.per_group, pre);
+        wgrad_presum_kernel<<<dim3((unsigned)((elems / 4 + 255) / 256), pl.groups), 256, 0, s>>>(pl.p.slab, pl.p.splits, elems, pl.per_group, pre);
         rsrc = pre;
         rsplits = pl.groups;
     }

@@ -20,6 +20,21 @@ __global__ void nchw_to_nhwc_kernel(const float* src, int B, int C, int H, int W
     }
 }
 
+// The image case: C <= 4 planes into a 4-channel pixel written as one 16-byte store (channels past C keep what the buffer held).
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* src, int B, int C, int H, int W, float* dst) {
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / plane, pix = i - b * plane;
+        f32x4 v = *reinterpret_cast<const f32x4*>(dst + i * 4);
+        const float* s0 = src + (b * C) * plane + pix;
+        v.x = s0[0];
+        if (C > 1) v.y = s0[plane];
+        if (C > 2) v.z = s0[2 * plane];
+        if (C > 3) v.w = s0[3 * plane];
+        *reinterpret_cast<f32x4*>(dst + i * 4) = v;
+    }
+}
+
 __global__ void nhwc_to_nchw_kernel(const float* src, int B, int C, int H, int W, int Cp, int choff, float* dst) {
     const size_t plane = (size_t)H * W, total = (size_t)B * plane;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -57,24 +72,26 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* stats, int
     }
 }
 
+constexpr int FIN_SL = 32;             // slice lanes of the finalize kernels: 32 channels x 32 slices = 1024 threads (short dependent-load chains)
+
 template <class TIn>
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const TIn* stats, int mtiles, int C, double count, const float* gamma, const float* beta,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const TIn* stats, int mtiles, int C, double count, const float* gamma, const float* beta,
                                                           float eps, float momentum, float* running_mean, float* running_var, float* scale,
                                                           float* shift, float* save_mean, float* save_invstd, int groups) {
-    __shared__ double s1[8][32], s2[8][32];
+    __shared__ double s1[FIN_SL][32], s2[FIN_SL][32];
     const int cl = threadIdx.x & 31, part = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     for (int g = 0; g < groups; ++g) {          // groups are finalised in order: running statistics see pass 0, then pass 1, ...
         const TIn* st = stats + (size_t)g * mtiles * 2 * C;
         double a = 0.0, b = 0.0;
         if (c < C)
-            for (int t = part; t < mtiles; t += 8) {
+            for (int t = part; t < mtiles; t += FIN_SL) {
                 a += (double)st[((size_t)t * 2 + 0) * C + c];
                 b += (double)st[((size_t)t * 2 + 1) * C + c];
             }
         s1[part][cl] = a; s2[part][cl] = b;
         __syncthreads();
         if (part == 0 && c < C) {
-            for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+            for (int k = 1; k < FIN_SL; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
             const double mean = a / count;
             double var = b / count - mean * mean;
             if (var < 0.0) var = 0.0;
@@ -158,23 +175,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* dy, con
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, float* dgamma, float* dbeta, int accumulate, float* sums,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* part, int nblk, int C, float* dgamma, float* dbeta, int accumulate, float* sums,
                                                               int groups) {
-    __shared__ double s1[8][32], s2[8][32];
+    __shared__ double s1[FIN_SL][32], s2[FIN_SL][32];
     const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     double ta = 0.0, tb = 0.0;
     for (int g = 0; g < groups; ++g) {
         const float* pg = part + (size_t)g * nblk * 2 * C;
         double a = 0.0, b = 0.0;
         if (c < C)
-            for (int k = slice; k < nblk; k += 8) {
+            for (int k = slice; k < nblk; k += FIN_SL) {
                 a += (double)pg[(size_t)k * 2 * C + c];
                 b += (double)pg[(size_t)k * 2 * C + C + c];
             }
         s1[slice][cl] = a; s2[slice][cl] = b;
         __syncthreads();
         if (slice == 0 && c < C) {
-            for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+            for (int k = 1; k < FIN_SL; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
             sums[(size_t)g * 2 * C + c] = (float)a;
             sums[(size_t)g * 2 * C + C + c] = (float)b;
             ta += a; tb += b;
@@ -336,7 +353,8 @@ using namespace mcav;
 
 MCAV_EXPORT int mcav_nchw_to_nhwc(const float* src, int B, int C, int H, int W, float* dst, int Cp, int choff, void* stream) {
     if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || choff < 0 || choff + C > Cp) return MCAV_E_INVALID;
-    nchw_to_nhwc_kernel<<<grid_for((size_t)B * H * W), 256, 0, as_stream(stream)>>>(src, B, C, H, W, dst, Cp, choff);
+    if (Cp == 4 && choff == 0) nchw_to_nhwc4_kernel<<<grid_for((size_t)B * H * W), 256, 0, as_stream(stream)>>>(src, B, C, H, W, dst);
+    else nchw_to_nhwc_kernel<<<grid_for((size_t)B * H * W), 256, 0, as_stream(stream)>>>(src, B, C, H, W, dst, Cp, choff);
     return launch_status();
 }
 
@@ -360,7 +378,7 @@ MCAV_EXPORT int mcav_bn_finalize(const float* stats, int mtiles, int C, double c
     if ((running_mean == nullptr) != (running_var == nullptr)) return MCAV_E_INVALID;
     hipStream_t s = as_stream(stream);
     if (mtiles <= BNF_DIRECT) {
-        bn_finalize_kernel<float><<<(C + 31) / 32, 256, 0, s>>>(stats, mtiles, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale,
+        bn_finalize_kernel<float><<<(C + 31) / 32, 32 * FIN_SL, 0, s>>>(stats, mtiles, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale,
                                                                 shift, save_mean, save_invstd, groups);
         return launch_status();
     }
@@ -370,7 +388,7 @@ MCAV_EXPORT int mcav_bn_finalize(const float* stats, int mtiles, int C, double c
     const int slices = (mtiles + per_slice - 1) / per_slice;
     double* part = reinterpret_cast<double*>(workspace);
     bn_partial_kernel<<<dim3((C + 63) / 64, slices, groups), 256, 0, s>>>(stats, mtiles, C, per_slice, part);
-    bn_finalize_kernel<double><<<(C + 31) / 32, 256, 0, s>>>(part, slices, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale,
+    bn_finalize_kernel<double><<<(C + 31) / 32, 32 * FIN_SL, 0, s>>>(part, slices, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale,
                                                              shift, save_mean, save_invstd, groups);
     return launch_status();
 }
@@ -415,7 +433,7 @@ MCAV_EXPORT int mcav_bn_bwd_reduce(const float* dy, const float* y_act, const fl
     hipStream_t s = as_stream(stream);
     bn_bwd_reduce_kernel<<<dim3(blocks, groups), 256, 0, s>>>((const f32x4*)dy, (const f32x4*)y_act, (const f32x4*)x, (const f32x4*)save_mean,
                                                               (const f32x4*)save_invstd, relu, pg, C4, part);
-    bn_bwd_finalize_kernel<<<(C + 31) / 32, 256, 0, s>>>(part, blocks, C, dgamma, dbeta, accumulate, sums, groups);
+    bn_bwd_finalize_kernel<<<(C + 31) / 32, 32 * FIN_SL, 0, s>>>(part, blocks, C, dgamma, dbeta, accumulate, sums, groups);
     return launch_status();
 }
 
