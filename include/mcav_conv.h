@@ -98,9 +98,10 @@ int mcav_pack_weights(const float* w_oihw, int Cout, int Cin, int kh, int kw, in
 
 /* The same for many filters in ONE launch.  items_dev: device array of nitems records
  *   { const float* src; float* dst; int Cout, Cin, taps, transposed, Np, Kp, Kstride, first_block; }   (48 bytes each)
- * where Kstride = taps * Kp rounded up to 16 and first_block is the running sum of ceil(Np * Kstride / 1024) over the
+ * where Kstride = taps * Kp rounded up to 16 and first_block is the running sum of mcav_pack_weights_blocks(...) over the
  * preceding records; nblocks = that sum over all records. */
 int mcav_pack_weights_multi(const void* items_dev, int nitems, int nblocks, void* stream);
+int mcav_pack_weights_blocks(int taps, int transposed, int Np, int Kp);   /* workgroups one record needs */
 
 /* 3x3 reflection-padded convolution with ONE output channel -- the decoder's disparity heads (reference
  * models/depth/resnet_dispnet.py:66-68 `dispconv`, layers.py:42-58 Conv3x3, applied with a sigmoid at :93-94).  HBM-bound

@@ -278,3 +278,27 @@ def test_halo_kernel_fused_upsample():
             da = N.conv_dgrad(spec, nhwc(dy), (2 * h, 2 * w_), n_begin=0, n_count=C, dact_aux=ad, dact=N.ACT_ELU, addend=nhwc(addend),
                               pool=True, tile=tile)
             assert rel_err(nchw(da), pre_a.grad + addend) < 2e-5
+
+
+def test_multi_pack_matches_single_pack():
+    """One-launch re-packing of every registered filter copy (LDS-tiled) == the per-filter pack kernel, bit for bit."""
+    from mcav import nn as N
+    g = torch.Generator().manual_seed(21)
+    shapes = [(64, 3, 7, True), (64, 64, 3, False), (128, 64, 1, False), (32, 96, 3, False), (16, 9, 7, False), (32, 16, 5, False),
+              (1, 16, 3, False), (12, 256, 1, False), (256, 128, 3, False)]
+    specs = []
+    for cout, cin, k, smallc in shapes:
+        w = torch.nn.Parameter(torch.randn(cout, cin, k, k, generator=g).to(DEV))
+        specs.append(N.ConvSpec(w, None, 1, k // 2, N.PAD_ZERO, smallc=smallc))
+    first = []
+    for s in specs:                                   # first request: the single-filter kernel
+        f = s.packed_fwd().clone()
+        b = None if s.smallc else s.packed_bwd().clone()
+        first.append((f, b))
+    with torch.no_grad():
+        for s in specs:
+            s.weight.add_(0.0)                        # same values, new version: every copy is now stale
+    for s, (f, b) in zip(specs, first):               # the first request re-derives ALL registered copies in one launch
+        assert torch.equal(s.packed_fwd(), f)
+        if b is not None:
+            assert torch.equal(s.packed_bwd(), b)

@@ -1331,34 +1331,67 @@ __global__ void pack_weights_kernel(const float* w, int Cout, int Cin, int taps,
 }
 
 // Many filters in one launch: after an optimiser step every packed copy is stale; one launch re-derives them all.
+// Both directions go through an LDS tile so that the OIHW reads and the packed writes are each contiguous:
+//   forward copy   : one block per packed row n (= output channel): its Cin x taps filter is one contiguous run;
+//   transposed copy: one block per (PK_CI input channels x 64 output channels) tile: 64 runs of PK_CI x taps floats in,
+//                    PK_CI x taps runs of 64 floats out.
 struct PackItem {
     const float* src;
     float* dst;
-    int Cout, Cin, taps, transposed, Np, Kp, Kstride, first_block;   // first_block: prefix sum of 256-thread blocks (4 elements per thread)
+    int Cout, Cin, taps, transposed, Np, Kp, Kstride, first_block;   // first_block: prefix sum of pack_blocks() over the preceding items
 };
 
+constexpr int PK_LDS = 12288;                 // floats of staging per block (48 KB)
+constexpr int PK_CO = 64;
+
+__host__ __device__ inline int pack_ci_tile(int taps) { const int t = 192 / taps; return t < 1 ? 1 : (t > 8 ? 8 : t); }
+
+__host__ __device__ inline int pack_blocks(int transposed, int taps, int Np, int Kp) {
+    if (!transposed) return Np;
+    const int ct = pack_ci_tile(taps);
+    return ((Np + ct - 1) / ct) * ((Kp + PK_CO - 1) / PK_CO);
+}
+
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem* items, int nitems) {
-    // binary search the item that owns this block
-    int lo = 0, hi = nitems - 1;
+    __shared__ float buf[PK_LDS];
+    int lo = 0, hi = nitems - 1;               // binary search the item that owns this block
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (items[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const PackItem it = items[lo];
-    const size_t total = (size_t)it.Np * it.Kstride;
-    const size_t base = ((size_t)(blockIdx.x - it.first_block) * 256 + threadIdx.x) * 4;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const size_t e = base + u;
-        if (e >= total) return;
-        const int n = (int)(e / it.Kstride), kf = (int)(e - (size_t)n * it.Kstride);
-        const int tap = kf / it.Kp, k = kf - tap * it.Kp;
-        float v = 0.f;
-        if (tap < it.taps) {
-            const int co = it.transposed ? k : n, ci = it.transposed ? n : k;
-            if (co < it.Cout && ci < it.Cin) v = it.src[((size_t)co * it.Cin + ci) * it.taps + tap];
+    const int bl = blockIdx.x - it.first_block, tid = threadIdx.x;
+    if (!it.transposed) {
+        const int n = bl, run = it.Cin * it.taps;
+        float* drow = it.dst + (size_t)n * it.Kstride;
+        const bool staged = run <= PK_LDS;
+        if (n < it.Cout && staged) {
+            const float* srow = it.src + (size_t)n * run;
+            for (int q = tid; q < run; q += 256) buf[q] = srow[q];
         }
-        it.dst[e] = v;
+        __syncthreads();
+        for (int kf = tid; kf < it.Kstride; kf += 256) {
+            const int tap = kf / it.Kp, k = kf - tap * it.Kp;
+            float v = 0.f;
+            if (n < it.Cout && tap < it.taps && k < it.Cin) v = staged ? buf[k * it.taps + tap] : it.src[((size_t)n * it.Cin + k) * it.taps + tap];
+            drow[kf] = v;
+        }
+        return;
+    }
+    const int ct = pack_ci_tile(it.taps), run = ct * it.taps, ld = run + 1;
+    const int cob = (it.Kp + PK_CO - 1) / PK_CO;
+    const int ci0 = (bl / cob) * ct, co0 = (bl % cob) * PK_CO;
+    for (int e = tid; e < PK_CO * run; e += 256) {
+        const int co = e / run, q = e - co * run;
+        float v = 0.f;
+        if (co0 + co < it.Cout && ci0 + q / it.taps < it.Cin) v = it.src[((size_t)(co0 + co) * it.Cin + ci0) * it.taps + q];
+        buf[co * ld + q] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < PK_CO * run; e += 256) {
+        const int q = e / PK_CO, co = e - q * PK_CO;      // q = r * taps + tap
+        const int r = q / it.taps, tap = q - r * it.taps;
+        if (ci0 + r < it.Np && co0 + co < it.Kp) it.dst[(size_t)(ci0 + r) * it.Kstride + tap * it.Kp + co0 + co] = buf[co * ld + q];
     }
 }
 
@@ -1372,6 +1405,7 @@ inline int pick_tile(const mcav_igemm_desc* d, long M) {
     if (d->n_count <= 32) return 3;
     // measured on MI355X (tools/conv_bench.py): small output tiles with 32-deep K-tiles win at every layer shape of the step --
     // more co-resident workgroups hide the load round trips, and a 32-deep tile halves the barriers per FLOP
+    if (d->mode != MCAV_G_SMALLC && ((M + 127) / 128) * ((d->n_count + 63) / 64) >= 1024) return 1;   // many rows (layer1, 48x160): 128x64 tiles, 104 vs 96 TF/s
     if (d->mode != MCAV_G_SMALLC && d->Kp % 64 == 0 && ((M + 63) / 64) * ((d->n_count + 63) / 64) < 512) return 11;   // few workgroups: deeper K-tiles
     if (d->mode != MCAV_G_SMALLC && d->Kp % 32 == 0) return 10;
     const long t128x64 = ((M + 127) / 128) * ((d->n_count + 63) / 64);
@@ -1655,6 +1689,11 @@ MCAV_EXPORT int mcav_pack_weights(const float* w_oihw, int Cout, int Cin, int kh
 }
 
 // items: device array of PackItem-compatible records {src, dst, Cout, Cin, taps, transposed, Np, Kp, Kstride, first_block}
+MCAV_EXPORT int mcav_pack_weights_blocks(int taps, int transposed, int Np, int Kp) {
+    if (taps <= 0 || Np <= 0 || Kp <= 0) return 0;
+    return pack_blocks(transposed, taps, Np, Kp);
+}
+
 MCAV_EXPORT int mcav_pack_weights_multi(const void* items_dev, int nitems, int nblocks, void* stream) {
     if (!items_dev || nitems <= 0 || nblocks <= 0) return MCAV_E_INVALID;
     pack_weights_multi_kernel<<<nblocks, 256, 0, as_stream(stream)>>>(reinterpret_cast<const PackItem*>(items_dev), nitems);

@@ -41,6 +41,7 @@ L.register({
     "mcav_wgrad": (c_i, [ctypes.POINTER(WgradDesc), c_p, c_sz, c_p]),
     "mcav_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "mcav_pack_weights_multi": (c_i, [c_p, c_i, c_i, c_p]),
+    "mcav_pack_weights_blocks": (c_i, [c_i, c_i, c_i, c_i]),
     "mcav_nchw_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "mcav_nhwc_to_nchw": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "mcav_bn_finalize": (c_i, [c_p, c_i, c_i, c_d, c_p, c_p, c_f, c_f] + [c_p] * 6 + [c_i, c_p, c_sz, c_p]),
@@ -132,7 +133,7 @@ class PackRegistry:
             it.src, it.dst = spec.weight.data_ptr(), buf.data_ptr()
             it.Cout, it.Cin, it.taps, it.transposed = spec.cout, spec.cin, spec.kh * spec.kw, int(tr)
             it.Np, it.Kp, it.Kstride, it.first_block = np_, kp_, buf.shape[1], blk
-            blk += (np_ * buf.shape[1] + 1023) // 1024
+            blk += L.lib().mcav_pack_weights_blocks(it.taps, int(tr), np_, kp_)
         raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
         self.table = raw.to(device)
         self.nblocks = blk
