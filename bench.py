@@ -94,9 +94,10 @@ def make_step(depth, pose, opt, crit, samples, pair=True, graph=False):
     if graph:
         make_step.graphed = runner is not fwd_bwd
 
-    def step():
+    def step(collective=True):
         loss = runner(tgt, refs[0], refs[1], K)
-        opt.grad_scale = mdist.allreduce_gradients(opt.arena())
+        # collective=False: rank 0's instrumented steps after the timed region (no other rank takes part in them)
+        opt.grad_scale = mdist.allreduce_gradients(opt.arena()) if collective else 1.0 / mdist.world()
         opt.step()
         return loss
     return step
@@ -142,13 +143,16 @@ def main():
     ap.set_defaults(graph=False)
     ap.add_argument("--layer-report", default=None, help="write a per-launch table of the instrumented step to this file")
     args = ap.parse_args()
+    if os.environ.get("MCAV_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit if the run exceeds N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MCAV_BENCH_WATCHDOG"]), exit=True)
 
     from mcav import dist as mdist
     from mcav import nn as N
-    rank, world = mdist.init_from_env("nccl")
+    rank, world = mdist.init_from_env(os.environ.get("MCAV_DIST_BACKEND", "nccl"))      # "gloo": rehearse the N > 1 flow on one GPU
     if world != args.gpus and not (world == 1 and args.gpus == 1):
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     B, H, W = args.batch, args.height, args.width
 
@@ -196,7 +200,7 @@ def main():
         N.PROFILE_LOSS = []
         N.PROFILE_TAGS = [] if args.layer_report else None
         for _ in range(3):
-            eager_step()                      # instrumented launches must be issued eagerly (events are not graph nodes)
+            eager_step(collective=False)      # instrumented launches must be issued eagerly (events are not graph nodes)
         torch.cuda.synchronize()
         recs, N.PROFILE = N.PROFILE, None
         streams.SERIAL = serial_before

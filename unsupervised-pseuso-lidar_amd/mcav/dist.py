@@ -26,10 +26,13 @@ def init_from_env(backend=None):
         return rank(), world()
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend=backend)
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, device_id=torch.device("cuda", local))      # bind the communicator to this rank's GPU
+    else:
+        dist.init_process_group(backend=backend)
     return rank(), world()
 
 
