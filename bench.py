@@ -95,8 +95,10 @@ def make_step(depth, pose, opt, crit, samples, pair=True, graph=False):
         make_step.graphed = runner is not fwd_bwd
 
     def step(collective=True):
-        loss = runner(tgt, refs[0], refs[1], K)
         # collective=False: rank 0's instrumented steps after the timed region (no other rank takes part in them)
+        hook, N.GRADS_READY = N.GRADS_READY, (N.GRADS_READY if collective else None)
+        loss = runner(tgt, refs[0], refs[1], K)
+        N.GRADS_READY = hook
         opt.grad_scale = mdist.allreduce_gradients(opt.arena()) if collective else 1.0 / mdist.world()
         opt.step()
         return loss
@@ -158,6 +160,8 @@ def main():
 
     depth, pose, opt, crit = build(device)
     mdist.broadcast_parameters(opt.arena())
+    if os.environ.get("MCAV_DP_OVERLAP", "1") != "0":
+        mdist.enable_overlap(opt.arena())          # N > 1: bucketed all-reduce behind the rest of backward (no-op on one rank)
     s = synthetic_samples(B, H, W, rank)
     samples = {"tgt": s["tgt"].to(device), "ref_imgs": [r.to(device) for r in s["ref_imgs"]], "intrinsics": s["intrinsics"].to(device)}
     step = make_step(depth, pose, opt, crit, samples, pair=not args.separate_passes, graph=args.graph)

@@ -56,3 +56,52 @@ def test_two_rank_gloo_allreduce_and_sharding():
     assert torch.equal(g0, g1) and s0 == s1 == 0.5          # summed gradients, 1/world for Adam
     assert float(g0[0]) == 3.0 and float(g0[16]) == 30.0    # 1+2 and 10+20 (second tensor starts at the 16-float slot)
     assert i0 == [0, 1, 2, 3, 4] and i1 == [5, 6, 7, 8, 9]  # disjoint equal slices, remainder dropped
+
+
+def _worker_overlap(rank, world, port, out):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from mcav import dist as mdist
+    from mcav import nn as N
+    from mcav.arena import Arena
+    mdist.init_from_env("gloo")
+    torch.manual_seed(7)
+    params = [torch.nn.Parameter(torch.randn(n)) for n in (5, 9, 16, 3, 8, 2)]
+    a = Arena(params)
+    mdist.enable_overlap(a)
+    assert N.GRADS_READY is not None
+    results = []
+    for step in range(2):                                  # two steps: the bucket bookkeeping resets
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        a.gflat.copy_(torch.randn(a.numel, generator=g))
+        N.grads_ready(params[3:5])                         # "decoder" announced first
+        N.grads_ready(params[1:3])                         # then another contiguous group
+        N.grads_ready([params[0], params[5]])              # not contiguous: ignored, left to finish()
+        N.grads_ready(params[2:4])                         # overlaps ranges already in flight: ignored
+        scale = mdist.allreduce_gradients(a)
+        results.append(a.gflat.clone())
+    out.put((rank, results, scale))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_overlap_equals_one_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, r0, s0), (_, r1, s1) = res
+    assert s0 == s1 == 0.5
+    numel = r0[0].numel()
+    for step in range(2):
+        want = sum(torch.randn(numel, generator=torch.Generator().manual_seed(1000 * step + r)) for r in range(2))
+        assert torch.equal(r0[step], r1[step])
+        assert torch.allclose(r0[step], want, rtol=0, atol=0)      # every element summed exactly once

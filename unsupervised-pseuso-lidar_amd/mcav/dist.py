@@ -42,11 +42,83 @@ def broadcast_parameters(arena, src=0):
         arena.bump()
 
 
+class GradSync:
+    """The gradient all-reduce, overlapped with backward in a few contiguous buckets of the flat arena.
+
+    A network's backward announces parameter groups whose gradients are final (`mcav.nn.grads_ready`: the decoder, then
+    encoder layer4 -- 70 % of the bytes are known with half of the backward still to run).  Each announcement all-reduces the
+    arena range those parameters span, asynchronously, ordered after the work issued so far on the announcing stream and on
+    the weight-gradient stream; `finish()` reduces whatever range was not announced and waits for everything.  Every rank
+    runs the same code, so the collectives are issued in the same order everywhere.  Summation is per element, so the
+    result is identical to one all-reduce of the whole arena."""
+
+    def __init__(self, arena):
+        self.arena = arena
+        self.works = []
+        self.done = []          # [lo, hi) ranges already handed to a collective this step
+
+    def span(self, params):
+        a = self.arena
+        index = {id(p): i for i, p in enumerate(a.params)}
+        idx = sorted(index[id(p)] for p in params if id(p) in index)
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            return None                                           # not one contiguous run of arena slots: leave it to finish()
+        last = idx[-1]
+        hi = a.offsets[last + 1] if last + 1 < len(a.offsets) else a.numel
+        return a.offsets[idx[0]], hi
+
+    def ready(self, params):
+        if world() <= 1:
+            return
+        r = self.span(params)
+        if r is None or any(not (r[1] <= lo or hi <= r[0]) for lo, hi in self.done):
+            return
+        from . import nn as N
+        buf = self.arena.gflat[r[0]:r[1]]
+        side = N.WGRAD_SIDE.stream if (buf.is_cuda and N.WGRAD_SIDE.forked) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())          # BatchNorm gradients are written on the calling stream
+            with torch.cuda.stream(side):                          # ... and the weight gradients on the wgrad stream, in order
+                self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+        self.done.append(r)
+
+    def finish(self):
+        """Call after backward() has returned (all streams joined).  Reduces the remaining ranges, then waits for all."""
+        if world() > 1:
+            pos = 0
+            for lo, hi in sorted(self.done) + [(self.arena.numel, self.arena.numel)]:
+                if lo > pos:
+                    self.works.append(dist.all_reduce(self.arena.gflat[pos:lo], op=dist.ReduceOp.SUM, async_op=True))
+                pos = max(pos, hi)
+            for w in self.works:
+                w.wait()
+        self.works, self.done = [], []
+
+
+_SYNC = {}
+
+
+def enable_overlap(arena):
+    """Overlap the gradient all-reduce of this arena with backward (no-op on one rank).  Returns the GradSync."""
+    from . import nn as N
+    gs = GradSync(arena)
+    _SYNC[id(arena)] = gs
+    N.GRADS_READY = gs.ready if world() > 1 else None
+    return gs
+
+
 def allreduce_gradients(arena):
-    """Sum the gradient arena over ranks (one collective).  Returns the scale Adam must apply (1/world)."""
+    """Sum the gradient arena over ranks.  Returns the scale Adam must apply (1/world).
+    One collective, or -- after enable_overlap(arena) -- the remainder of the bucketed, backward-overlapped reduction."""
     w = world()
     if w > 1:
-        dist.all_reduce(arena.gflat, op=dist.ReduceOp.SUM)
+        gs = _SYNC.get(id(arena))
+        if gs is not None and gs.arena is arena:
+            gs.finish()
+        else:
+            dist.all_reduce(arena.gflat, op=dist.ReduceOp.SUM)
     return 1.0 / w
 
 

@@ -380,6 +380,16 @@ class _WgradSide:
 
 WGRAD_SIDE = _WgradSide()
 
+# Data parallelism (mcav/dist.py:GradSync): called from a network's backward when every gradient of a group of parameters has
+# been ISSUED (weight gradients on the wgrad stream, BatchNorm gradients on the calling stream), so that their slice of the
+# gradient arena can be all-reduced while the rest of the backward pass still runs.  None on a single GPU.
+GRADS_READY = None
+
+
+def grads_ready(params):
+    if GRADS_READY is not None:
+        GRADS_READY(list(params))
+
 
 def launch_wgrad(d, tensors, flops=0.0, tag=""):
     """mcav_wgrad for a filled descriptor (workspace handling + stream choice).  tensors: what the launch reads."""

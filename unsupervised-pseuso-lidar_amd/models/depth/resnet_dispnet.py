@@ -210,7 +210,8 @@ class _DispResNetPairFn(torch.autograd.Function):
             gb = torch.zeros_like(ref) if gb is None else gb
         g = torch.cat([L.dev(ga.contiguous(), "grad"), L.dev(gb.contiguous(), "grad")], 0)
         dfe = E.decoder_backward(mod.decoder, ctx.dsv, {0: g.view(g.shape[0], g.shape[2], g.shape[3], 1)})
-        E.encoder_backward(mod.encoder.encoder, ctx.esv, dfe)
+        N.grads_ready(mod.decoder.parameters())        # both passes are in this one backward: the decoder's gradients are final
+        E.encoder_backward(mod.encoder.encoder, ctx.esv, dfe, complete=True)
         ctx.esv = ctx.dsv = None
         return (None, None, None) + (None,) * len(list(mod.parameters()))
 

@@ -61,6 +61,8 @@ class Trainer:
         self.model_optimizer = FusedAdam(parameters_train, self.learning_rate)
         self.model_lr_scheduler = torch.optim.lr_scheduler.StepLR(self.model_optimizer, self.scheduler_step_size, self.gamma)
         mdist.broadcast_parameters(self.model_optimizer.arena())
+        if os.environ.get("MCAV_DP_OVERLAP", "1") != "0":
+            mdist.enable_overlap(self.model_optimizer.arena())      # N > 1: the all-reduce hides behind the rest of backward
 
         self.criterion = Losses()
         from mcav.streams import Branch
