@@ -48,7 +48,9 @@ using Tile64x64k64 = Tile<64, 64, 32, 32, 32, 64>;       // 64-deep: 32 MFMAs pe
 // destination pixel of GEMM row m: returns false for padding rows.
 __device__ __forceinline__ bool decode_row(const IgemmParams& p, int m, int& n, int& dy, int& dx) {
     if (p.g.mode == MCAV_G_ADJ_STRIDE2) {
-        const int cls = m / p.McP, r = m - cls * p.McP;
+        // row blocks hold the parity classes in the order 3, 2, 1, 0: class (1,1) visits four taps of a 3x3 filter, class (0,0) one --
+        // the long tiles are dispatched first and the short ones fill the tail
+        const int blk = m / p.McP, r = m - blk * p.McP, cls = 3 - blk;
         if (r >= p.Mc) return false;
         const int Hc = (p.Hd + 1) >> 1, Wc = (p.Wd + 1) >> 1;
         n = r / (Hc * Wc);
@@ -192,7 +194,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     __shared__ int s_rn[KIND == K_GENERIC ? 1 : BM], s_ry[KIND == K_GENERIC ? 1 : BM], s_rx[KIND == K_GENERIC ? 1 : BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    // The XCD remap gives each XCD one contiguous run of tiles.  Parity-class tiles differ 4x in work per class, and a run is
+    // (mostly) one class: there the hardware's round-robin over XCDs is kept, so every XCD gets the same mix, long tiles first.
+    const int lid = p.g.mode == MCAV_G_ADJ_STRIDE2 ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     const int nt = lid % p.ntiles, mt = lid / p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const GatherSrc& g = p.g;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     // ---- K-tile enumeration: (tap, chunk); ADJ_STRIDE2 tiles only visit the taps of their parity class
     const int nchunks = g.mode == MCAV_G_SMALLC ? 1 : p.Kp / CK;
     int cls_py = 0, cls_px = 0;
-    if (KIND != K_REFLADJ && g.mode == MCAV_G_ADJ_STRIDE2) { const int cls = m0 / p.McP; cls_py = cls >> 1; cls_px = cls & 1; }
+    if (KIND != K_REFLADJ && g.mode == MCAV_G_ADJ_STRIDE2) { const int cls = 3 - m0 / p.McP; cls_py = cls >> 1; cls_px = cls & 1; }
     auto tap_ok = [&](int tap) -> bool {
         if (KIND == K_REFLADJ || g.mode != MCAV_G_ADJ_STRIDE2) return true;
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
@@ -523,7 +527,9 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     __shared__ int s_nt;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    // The XCD remap gives each XCD one contiguous run of tiles.  Parity-class tiles differ 4x in work per class, and a run is
+    // (mostly) one class: there the hardware's round-robin over XCDs is kept, so every XCD gets the same mix, long tiles first.
+    const int lid = p.g.mode == MCAV_G_ADJ_STRIDE2 ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     const int nt = lid % p.ntiles, mt = lid / p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const GatherSrc& g = p.g;
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     if (tid == 0) {      // ADJ_STRIDE2 tiles hold one parity class of destination pixels and visit only that class's taps
         int nv = 0;
         const bool adj = g.mode == MCAV_G_ADJ_STRIDE2;
-        const int cls = adj ? m0 / p.McP : 0, cpy = cls >> 1, cpx = cls & 1;
+        const int cls = adj ? 3 - m0 / p.McP : 0, cpy = cls >> 1, cpx = cls & 1;
         for (int t = 0; t < p.taps; ++t) {
             const int ky = t / p.kw, kx = t - ky * p.kw;
             if (!adj || (((cpy + g.offset - ky) | (cpx + g.offset - kx)) & 1) == 0) s_tl[nv++] = t;
