@@ -97,6 +97,28 @@ int mcav_smooth_loss_fwd_bwd(const float* depth, int B, int H, int W, float weig
                              float* loss_accum, float* d_depth, int accumulate,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- after the training step ------------------------------------------------------------------ */
+
+/* Depth metrics, reference evaluate.py:6-39 (compute_errors): one pass over the ground-truth depth and the network's sigmoid
+ * disparity (depth = 1 / (10 disp + 0.01), pose_geometry.py:82-83), float32 per element as the reference, float64 sums.
+ * out10 (device) = { silog, abs_rel, log10, rms, sq_rel, log_rms, d1, d2, d3, number of elements taken }.  sq_rel is the real
+ * mean((gt-pred)^2 / gt); the reference returns rms under that key (evaluate.py:36).  Elements with gt <= min_gt are skipped
+ * (KITTI ground truth is sparse); min_gt < 0 takes every element, as the reference does. */
+size_t mcav_depth_metrics_workspace_bytes(void);
+int mcav_depth_metrics(const float* gt, const float* disp, size_t n, float min_gt, float* out10, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* Depth image -> pseudo-LiDAR cloud, reference pseudo-lidar/utils/PseudoLiDAR.py:69-110 (project_PL) with :39-46
+ * (inverse_rigid_trans): un-project with P_rect_02, transform into the velodyne frame, keep x >= 0 and z < 1 m, keep every
+ * sparsity-th survivor (0 = all), in pixel order; float64 like the reference's numpy arithmetic; 4th column 0 as in the reference.
+ * depth [rows, cols] float32 on the device; T_velo_to_cam (4x4) and P_rect (3x4) are HOST pointers, row-major doubles.
+ * cloud: device [capacity_points][4] doubles (rows * cols is always enough).  count_out_dev (device unsigned) receives the number of
+ * valid points BEFORE sparsification: the cloud has ceil(count / max(sparsity, 1)) rows. */
+size_t mcav_pseudo_lidar_workspace_bytes(int rows, int cols);
+int mcav_pseudo_lidar_project(const float* depth, int rows, int cols, const double* T_velo_to_cam, const double* P_rect, int sparsity,
+                              double* cloud, size_t capacity_points, unsigned* count_out_dev, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -283,7 +283,50 @@ def case_posefc():
     return {k: list(v.shape) for k, v in m.state_dict().items()}
 
 
+def case_metrics():
+    """evaluate.compute_errors (evaluate.py:6-39).  The function is broken as written: disp_to_depth(pred[0]) returns a nested list and
+    .cpu() on it raises.  Harness-side shim (reference file untouched): the module-global name `disp_to_depth` it looks up is pointed
+    at a wrapper that runs the REFERENCE's disp_to_depth on [[tensor]] and unwraps the result; pred is passed as [tensor]."""
+    import evaluate as ref_eval
+    ref_eval.disp_to_depth = lambda t: ref_pg.disp_to_depth([[t]])[0][0]
+    g = torch.Generator().manual_seed(71)
+    gt = 1.0 + 40.0 * torch.rand(2, 1, 24, 40, generator=g)
+    disp = (1.0 / gt - 0.01) / 10.0 * (1.0 + 0.25 * torch.randn(gt.shape, generator=g)).clamp(0.3, 3.0)
+    disp = disp.clamp(1e-4, 1.0)
+    acc = ref_eval.compute_errors(gt, [disp])
+    save("metrics.npz", gt=npy(gt), disp=npy(disp), **{k: np.float64(v) for k, v in acc.items()})
+
+
+def case_pseudo_lidar():
+    """PseudoLiDAR.project_PL (pseudo-lidar/utils/PseudoLiDAR.py:69-110) called on the reference class itself; __init__ only reads
+    calibration files into T and P, which are set directly here (KITTI-like values)."""
+    sys.path.insert(0, os.path.join(REF, "pseudo-lidar", "utils"))
+    import PseudoLiDAR as ref_pl
+    rng = np.random.RandomState(5)
+    R = np.array([[7.533745e-03, -9.999714e-01, -6.166020e-04], [1.480249e-02, 7.280733e-04, -9.998902e-01],
+                  [9.998621e-01, 7.523790e-03, 1.480755e-02]])          # KITTI calib_velo_to_cam-like (camera z = velodyne x)
+    T = np.vstack([np.concatenate((R, np.array([[-4.069766e-03], [-7.631618e-02], [-2.717806e-01]])), axis=1), [0, 0, 0, 1]])
+    out = {}
+    for name, (rows, cols, sparsity) in {"a": (24, 78, 0), "b": (37, 61, 3), "c": (16, 40, 7)}.items():
+        # P_rect_02-like, scaled to the small image (principal point at its centre: rows above it rise past the 1 m cut with depth)
+        P = np.array([[60.0, 0.0, cols / 2.0, 4.485728e+01 / 12], [0.0, 60.0, rows / 2.0, 2.163791e-01 / 12], [0.0, 0.0, 1.0, 2.745884e-03]])
+        depth = (2.0 + 60.0 * rng.rand(rows, cols)).astype(np.float32)
+        pl = object.__new__(ref_pl.PseudoLiDAR)
+        pl.T, pl.P, pl.sparsity = T, P, sparsity
+        out["P_" + name] = P
+        out["depth_" + name] = depth
+        out["cloud_" + name] = pl.project_PL(depth)
+        out["sparsity_" + name] = np.int64(sparsity)
+    save("pseudo_lidar.npz", T=T, **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:          # regenerate selected cases only: python tests/golden/make_golden.py case_metrics case_pseudo_lidar
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
+    case_metrics()
+    case_pseudo_lidar()
     case_loss_small()
     case_loss_ka1()
     case_warp_edge()

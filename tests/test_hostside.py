@@ -83,3 +83,34 @@ def test_synthetic_dataset_sample_contract():
     s = ds[3]
     assert s["tgt"].shape == (3, 192, 640) and len(s["ref_imgs"]) == 2 and s["intrinsics"].dtype == torch.float64
     assert torch.equal(ds[3]["tgt"], s["tgt"])
+
+
+def test_fused_adam_loads_a_torch_adam_checkpoint():
+    """The reference checkpoint's 'optimizer_state_dict' (torch.optim.Adam, trainer.py:136) loads into the fused optimiser:
+    moments land in the flat buffers the kernel reads, the step count is restored, and the dict written back has Adam's format."""
+    from mcav.optim import FusedAdam
+    torch.manual_seed(3)
+    shapes = [(4, 3, 3, 3), (4,), (2, 4, 1, 1)]
+    ref_params = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+    ref = torch.optim.Adam(ref_params, lr=1e-3)
+    for _ in range(3):
+        for p in ref_params:
+            p.grad = torch.randn_like(p)
+        ref.step()
+    sd = ref.state_dict()
+    mine_params = [torch.nn.Parameter(p.detach().clone()) for p in ref_params]
+    opt = FusedAdam(mine_params, lr=5e-4)
+    opt.load_state_dict(sd)
+    a = opt.arena()
+    assert opt._step == 3 and opt.param_groups[0]["lr"] == 1e-3
+    for p, o, q in zip(a.params, a.offsets, ref_params):
+        n = p.numel()
+        assert torch.equal(opt._m[o:o + n], ref.state[q]["exp_avg"].reshape(-1))
+        assert torch.equal(opt._v[o:o + n], ref.state[q]["exp_avg_sq"].reshape(-1))
+        assert opt.state[p]["exp_avg"].data_ptr() == opt._m[o:o + n].data_ptr()       # still views of the flat buffers
+    back = opt.state_dict()
+    fresh = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in ref_params], lr=1.0)
+    fresh.load_state_dict(back)                                                            # and Adam accepts what we write
+    for q, f in zip(ref_params, fresh.param_groups[0]["params"]):
+        assert torch.equal(fresh.state[f]["exp_avg"], ref.state[q]["exp_avg"])
+        assert float(fresh.state[f]["step"]) == 3.0

@@ -208,3 +208,24 @@ def test_state_dict_keys():
     for name, m in models.items():
         got = {k: list(v.shape) for k, v in m.state_dict().items()}
         assert got == want[name], name
+
+
+def test_metrics_oracle_vs_reference():
+    """oracle.evaluate.compute_errors == the reference's compute_errors (evaluate.py:6-39, quirk 'sq_rel' = rms included)."""
+    from oracle import evaluate as oe
+    g = np.load(os.path.join(GOLDEN, "metrics.npz"))
+    got = oe.compute_errors(g["gt"], g["disp"])
+    for k in ("silog", "abs_rel", "log10", "rms", "sq_rel", "log_rms", "d1", "d2", "d3"):
+        assert abs(float(got[k]) - float(g[k])) <= 1e-6 * max(1.0, abs(float(g[k]))), k
+    assert got["sq_rel"] == got["rms"] and got["sq_rel_fixed"] != got["rms"]
+
+
+def test_pseudo_lidar_oracle_vs_reference():
+    """oracle.pseudo_lidar.project_PL == PseudoLiDAR.project_PL (pseudo-lidar/utils/PseudoLiDAR.py:69-110), bit for bit (same numpy ops)."""
+    from oracle import pseudo_lidar as op
+    g = np.load(os.path.join(GOLDEN, "pseudo_lidar.npz"))
+    for name in "abc":
+        got = op.project_PL(g["depth_" + name], g["T"], g["P_" + name], int(g["sparsity_" + name]))
+        assert got.shape == g["cloud_" + name].shape and got.dtype == np.float64
+        assert np.array_equal(got, g["cloud_" + name])
+        assert np.all(got[:, 3] == 0.0)          # the reference's inverse_rigid_trans leaves the homogeneous row zero

@@ -1,0 +1,75 @@
+"""GPU: the steps after the training step: depth metrics and the depth -> pseudo-LiDAR projection, through the C ABI,
+against the oracle and the golden vectors captured from the reference (evaluate.py:6-39, pseudo-lidar/utils/PseudoLiDAR.py:69-110)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_depth_metrics_vs_reference_golden():
+    from evaluate import compute_errors
+    g = np.load(os.path.join(GOLDEN, "metrics.npz"))
+    gt, disp = torch.from_numpy(g["gt"]).to(DEV), torch.from_numpy(g["disp"]).to(DEV)
+    acc = compute_errors(gt, [disp])
+    assert acc["count"] == gt.numel()
+    for k in ("abs_rel", "log10", "rms", "log_rms", "d1", "d2", "d3"):
+        assert abs(acc[k] - float(g[k])) <= 2e-5 * max(1.0, abs(float(g[k]))), k
+    assert abs(acc["silog"] - float(g["silog"])) <= 1e-4 * float(g["silog"])      # mean(e^2) - mean(e)^2: float32 cancellation in the reference
+    # the reference stores rms under 'sq_rel' (evaluate.py:36); here it is the squared-relative error (oracle's sq_rel_fixed)
+    from oracle import evaluate as oe
+    want = oe.compute_errors(g["gt"], g["disp"])
+    assert abs(acc["sq_rel"] - float(want["sq_rel_fixed"])) <= 2e-5 * float(want["sq_rel_fixed"])
+
+
+def test_depth_metrics_mask_and_size():
+    """Sparse ground truth: only gt > min_gt counts; 1.2 M elements (a 4 x 375 x 1242 KITTI batch is 1.9 M) against the oracle in float64."""
+    from evaluate import compute_errors
+    from oracle import evaluate as oe
+    g = torch.Generator().manual_seed(5)
+    gt = 1.0 + 79.0 * torch.rand(3, 1, 320, 1248, generator=g)
+    gt[torch.rand(gt.shape, generator=g) < 0.7] = 0.0                              # 70 % of the pixels have no LiDAR return
+    disp = ((1.0 / gt.clamp_min(1.0) - 0.01) / 10.0 * (1.0 + 0.2 * torch.randn(gt.shape, generator=g))).clamp(1e-4, 1.0)
+    acc = compute_errors(gt.to(DEV), disp.to(DEV), min_gt=1e-3)
+    m = gt > 1e-3
+    want = oe.compute_errors(gt[m].numpy().astype(np.float64), disp[m].numpy().astype(np.float64))
+    assert acc["count"] == int(m.sum())
+    for k in ("abs_rel", "log10", "rms", "log_rms", "d1", "d2", "d3", "silog"):
+        assert abs(acc[k] - float(want[k])) <= 1e-4 * max(1.0, abs(float(want[k]))), k
+
+
+def test_pseudo_lidar_vs_reference_golden():
+    from pseudo_lidar import PseudoLiDAR
+    g = np.load(os.path.join(GOLDEN, "pseudo_lidar.npz"))
+    for name in "abc":
+        pl = PseudoLiDAR.from_matrices(g["T"], g["P_" + name], int(g["sparsity_" + name]))
+        got = pl.project_PL(torch.from_numpy(g["depth_" + name]).to(DEV)).cpu().numpy()
+        want = g["cloud_" + name]
+        assert got.shape == want.shape and got.dtype == np.float64          # same points kept, same order, same sparsification
+        assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, np.max(np.abs(want)))
+
+
+def test_pseudo_lidar_full_size_properties():
+    """375 x 1242 (KITTI): count and order against the oracle, idempotent re-run, sparsity k keeps exactly every k-th survivor."""
+    from oracle import pseudo_lidar as op
+    from pseudo_lidar import PseudoLiDAR
+    g = np.load(os.path.join(GOLDEN, "pseudo_lidar.npz"))
+    rng = np.random.RandomState(9)
+    rows, cols = 375, 1242
+    depth = (1.5 + 78.0 * rng.rand(rows, cols)).astype(np.float32)
+    P = np.array([[7.215377e+02, 0.0, 6.095593e+02, 4.485728e+01], [0.0, 7.215377e+02, 1.728540e+02, 2.163791e-01], [0.0, 0.0, 1.0, 2.745884e-03]])
+    d = torch.from_numpy(depth).to(DEV)
+    full = PseudoLiDAR.from_matrices(g["T"], P, 0).project_PL(d)
+    want = op.project_PL(depth, g["T"], P, 0)
+    assert tuple(full.shape) == want.shape
+    assert np.max(np.abs(full.cpu().numpy() - want)) <= 1e-11
+    again = PseudoLiDAR.from_matrices(g["T"], P, 0).project_PL(d)
+    assert torch.equal(full, again)
+    for k in (2, 5, 64):
+        sp = PseudoLiDAR.from_matrices(g["T"], P, k).project_PL(d)
+        assert torch.equal(sp, full[0::k])

@@ -42,3 +42,22 @@ class FusedAdam(torch.optim.Optimizer):
                                        self.grad_scale, L.stream()), "mcav_adam_step")
         a.bump()
         self._step_t.fill_(float(self._step))
+
+    def load_state_dict(self, state_dict):
+        """Accepts the dict torch.optim.Adam writes (reference trainer.py:136,148: 'optimizer_state_dict' of a checkpoint):
+        the moments are copied INTO the flat buffers (the fused kernel keeps reading those) and the step count is restored."""
+        a = self.arena()                       # first: creating the arena (re)initialises the per-parameter state entries
+        super().load_state_dict(state_dict)
+        step = 0
+        for p, o in zip(a.params, a.offsets):
+            st = self.state.get(p)
+            n = p.numel()
+            if st:
+                if "exp_avg" in st:
+                    self._m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                    self._v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                if "step" in st:
+                    step = max(step, int(float(st["step"])))
+            self.state[p] = {"step": self._step_t, "exp_avg": self._m[o:o + n].view(p.shape), "exp_avg_sq": self._v[o:o + n].view(p.shape)}
+        self._step = step
+        self._step_t.fill_(float(step))

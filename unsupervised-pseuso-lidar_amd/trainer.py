@@ -190,6 +190,8 @@ class Trainer:
         acc = None
         for samples in self.validation_loader:
             outputs = self.process_batch(samples, warp_test=True)
-            acc = compute_errors(samples['groundtruth'].clamp_min(1e-3), outputs[0][0][0])
+            # reference trainer.py:325-329: compute_errors(gt, outputs[0]); the ground truth goes to the GPU, pixels without one are skipped
+            gt = samples['groundtruth'].to(self.device, non_blocking=True)
+            acc = compute_errors(gt, outputs[0][0], min_gt=1e-3)
         self.set_train()
         return acc
