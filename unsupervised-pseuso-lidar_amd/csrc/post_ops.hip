@@ -12,34 +12,52 @@ namespace mcav {
 // sums: 0 d1, 1 d2, 2 d3 (counts), 3 (gt-pred)^2, 4 (ln gt - ln pred)^2, 5 |gt-pred|/gt, 6 (gt-pred)^2/gt, 7 err, 8 err^2, 9 |log10|,
 //       10 number of elements taken
 constexpr int NMET = 11;
-constexpr int MET_BLOCKS = 512;
+constexpr int MET_BLOCKS = 2048;
 
+typedef float mf32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void met_accum(float g, float dsp, float min_gt, double (&s)[NMET]) {
+    if (!(g > min_gt)) return;                              // min_gt < 0: every element, as the reference
+    const float p = 1.0f / (10.0f * dsp + 0.01f);           // pose_geometry.py:82-83
+    const float t = fmaxf(g / p, p / g);
+    s[0] += t < 1.25f ? 1.0 : 0.0;
+    s[1] += t < 1.25f * 1.25f ? 1.0 : 0.0;
+    s[2] += t < 1.25f * 1.25f * 1.25f ? 1.0 : 0.0;
+    const float d = g - p;
+    const float lg = logf(g), lp = logf(p);
+    s[3] += (double)(d * d);
+    s[4] += (double)((lg - lp) * (lg - lp));
+    s[5] += (double)(fabsf(d) / g);
+    s[6] += (double)(d * d / g);
+    const float e = lp - lg;
+    s[7] += (double)e;
+    s[8] += (double)(e * e);
+    s[9] += (double)fabsf(log10f(p) - log10f(g));
+    s[10] += 1.0;
+}
+
+// 16-byte loads, two of each array in flight per lane and iteration (the pass is latency-bound otherwise: 8 B per element)
 __global__ __launch_bounds__(256) void depth_metrics_partial_kernel(const float* __restrict__ gt, const float* __restrict__ disp, size_t n,
                                                                     float min_gt, double* __restrict__ part) {
     __shared__ double red[4][NMET];
     double s[NMET];
 #pragma unroll
     for (int k = 0; k < NMET; ++k) s[k] = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float g = gt[i];
-        if (!(g > min_gt)) continue;                            // min_gt < 0: every element, as the reference
-        const float p = 1.0f / (10.0f * disp[i] + 0.01f);       // pose_geometry.py:82-83
-        const float t = fmaxf(g / p, p / g);
-        s[0] += t < 1.25f ? 1.0 : 0.0;
-        s[1] += t < 1.25f * 1.25f ? 1.0 : 0.0;
-        s[2] += t < 1.25f * 1.25f * 1.25f ? 1.0 : 0.0;
-        const float d = g - p;
-        const float lg = logf(g), lp = logf(p);
-        s[3] += (double)(d * d);
-        s[4] += (double)((lg - lp) * (lg - lp));
-        s[5] += (double)(fabsf(d) / g);
-        s[6] += (double)(d * d / g);
-        const float e = lp - lg;
-        s[7] += (double)e;
-        s[8] += (double)(e * e);
-        s[9] += (double)fabsf(log10f(p) - log10f(g));
-        s[10] += 1.0;
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * 256;
+    const mf32x4* g4 = reinterpret_cast<const mf32x4*>(gt);
+    const mf32x4* d4 = reinterpret_cast<const mf32x4*>(disp);
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        const mf32x4 ga = g4[i], da = d4[i], gb = g4[i + stride], db = d4[i + stride];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { met_accum(ga[c], da[c], min_gt, s); met_accum(gb[c], db[c], min_gt, s); }
     }
+    if (i < n4) {
+        const mf32x4 ga = g4[i], da = d4[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) met_accum(ga[c], da[c], min_gt, s);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) met_accum(gt[n4 * 4 + threadIdx.x], disp[n4 * 4 + threadIdx.x], min_gt, s);      // ragged tail
 #pragma unroll
     for (int k = 0; k < NMET; ++k) {
         double v = s[k];
@@ -51,13 +69,23 @@ __global__ __launch_bounds__(256) void depth_metrics_partial_kernel(const float*
 }
 
 // out[9] in the reference's key order: silog, abs_rel, log10, rms, sq_rel, log_rms, d1, d2, d3; out[9] = element count
-__global__ void depth_metrics_finalize_kernel(const double* part, int blocks, float* out) {
+__global__ __launch_bounds__(256) void depth_metrics_finalize_kernel(const double* part, int blocks, float* out) {
+    __shared__ double red[4][NMET];
     __shared__ double tot[NMET];
-    if (threadIdx.x < NMET) {
-        double v = 0.0;
-        for (int b = 0; b < blocks; ++b) v += part[(size_t)b * NMET + threadIdx.x];
-        tot[threadIdx.x] = v;
+    double s[NMET];
+#pragma unroll
+    for (int k = 0; k < NMET; ++k) s[k] = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += 256)
+#pragma unroll
+        for (int k = 0; k < NMET; ++k) s[k] += part[(size_t)b * NMET + k];
+#pragma unroll
+    for (int k = 0; k < NMET; ++k) {
+        double v = s[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
     }
+    __syncthreads();
+    if (threadIdx.x < NMET) tot[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     __syncthreads();
     if (threadIdx.x == 0) {
         const double n = tot[10] > 0.0 ? tot[10] : 1.0;
@@ -167,11 +195,13 @@ MCAV_EXPORT int mcav_depth_metrics(const float* gt, const float* disp, size_t n,
     if (!gt || !disp || !out10 || !workspace || n == 0) return MCAV_E_INVALID;
     if (workspace_bytes < mcav_depth_metrics_workspace_bytes()) return MCAV_E_WORKSPACE;
     hipStream_t s = as_stream(stream);
-    size_t blocks = (n + 255) / 256;
+    if ((reinterpret_cast<uintptr_t>(gt) | reinterpret_cast<uintptr_t>(disp)) & 15) return MCAV_E_INVALID;      // 16-byte loads
+    size_t blocks = (n / 4 + 511) / 512;              // two 16-byte pieces per lane and iteration
+    if (blocks < 1) blocks = 1;
     if (blocks > MET_BLOCKS) blocks = MET_BLOCKS;
     double* part = reinterpret_cast<double*>(workspace);
     depth_metrics_partial_kernel<<<(int)blocks, 256, 0, s>>>(gt, disp, n, min_gt, part);
-    depth_metrics_finalize_kernel<<<1, 64, 0, s>>>(part, (int)blocks, out10);
+    depth_metrics_finalize_kernel<<<1, 256, 0, s>>>(part, (int)blocks, out10);
     return launch_status();
 }
 
