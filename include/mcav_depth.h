@@ -119,6 +119,20 @@ int mcav_pseudo_lidar_project(const float* depth, int rows, int cols, const doub
                               double* cloud, size_t capacity_points, unsigned* count_out_dev, void* workspace, size_t workspace_bytes,
                               void* stream);
 
+/* ---- before the training step ------------------------------------------------------------------------ */
+
+/* The reference's image transform chain (dataloaders.py:32-49 load_img, trainer.py:97-103): decoded uint8 RGB -> /255 -> ToTensor ->
+ * ToPILImage -> Resize((h, w)) [Pillow bilinear, antialiased, 8-bit fixed point, horizontal then vertical] -> ToTensor -> Normalize,
+ * for a batch of equally sized images, bit-exact against Pillow's resize.
+ * mcav_resample_coeffs (HOST): Pillow's coefficient tables for one axis; call it with kk = NULL to get the capacity (out_size * ksize)
+ * and *ksize_out, then again with host arrays bounds[out_size * 2], kk[capacity]; copy both to the device for mcav_image_preprocess.
+ * An axis whose size does not change still takes its (identity) table. */
+int mcav_resample_coeffs(int in_size, int out_size, int* ksize_out, int* bounds, int* kk, int kk_capacity);
+size_t mcav_image_preprocess_workspace_bytes(int B, int H0, int w);
+int mcav_image_preprocess(const unsigned char* src_bhwc, int B, int H0, int W0, int h, int w, const int* hbounds, const int* hkk, int hksize,
+                          const int* vbounds, const int* vkk, int vksize, const float* mean3, const float* std3, float* dst_bchw,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -320,6 +320,32 @@ def case_pseudo_lidar():
     save("pseudo_lidar.npz", T=T, **out)
 
 
+def case_preprocess():
+    """The image transform chain of dataloaders.py:32-49 / trainer.py:97-103.  torchvision is not installed: its four transforms are
+    applied through what they call (documented 0.9.1 behaviour): ToTensor(float HWC array) = transpose; ToPILImage(float tensor) =
+    mul(255).byte() -> PIL RGB; Resize((h, w)) on a PIL image = Image.resize((w, h), BILINEAR) -- run with the INSTALLED Pillow, the
+    library the reference itself calls; ToTensor(PIL) = byte / 255; Normalize = (x - mean) / std."""
+    from PIL import Image
+    rng = np.random.RandomState(17)
+    out = {}
+    for name, (h0, w0, h, w) in {"down": (75, 248, 40, 128), "up": (20, 33, 45, 80), "mixed": (37, 61, 37, 30), "kitti": (94, 311, 48, 160)}.items():
+        yy, xx = np.mgrid[0:h0, 0:w0]
+        base = 127 + 90 * np.sin(yy[..., None] / 7.0 + np.arange(3)) * np.cos(xx[..., None] / 11.0)      # smooth image + noise
+        img = np.clip(base + 25 * rng.randn(h0, w0, 3), 0, 255).astype(np.uint8)
+        f = np.asarray(img, dtype=np.float32) / 255.0                                   # dataloaders.py:33,38
+        t = torch.from_numpy(f.transpose(2, 0, 1))                                      # ToTensor on a float array
+        pil = Image.fromarray(np.transpose(t.mul(255).byte().numpy(), (1, 2, 0)))       # ToPILImage
+        small = np.asarray(pil.resize((w, h), Image.BILINEAR))                          # Resize
+        x = torch.from_numpy(small.transpose(2, 0, 1).copy()).to(torch.float32).div(255)          # ToTensor on a PIL image
+        mean = torch.tensor((0.485, 0.456, 0.406)).view(3, 1, 1)
+        std = torch.tensor((0.229, 0.224, 0.225)).view(3, 1, 1)
+        out["img_" + name] = img
+        out["resized_" + name] = small
+        out["out_" + name] = npy((x - mean) / std)                                      # Normalize
+    import PIL
+    save("preprocess.npz", pillow_version=np.array(PIL.__version__), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # regenerate selected cases only: python tests/golden/make_golden.py case_metrics case_pseudo_lidar
         for name in sys.argv[1:]:

@@ -43,6 +43,7 @@ def test_python_binding_covers_header():
     import mcav.tape  # noqa: F401
     import evaluate  # noqa: F401
     import pseudo_lidar  # noqa: F401
+    import dataloaders  # noqa: F401
     missing = [n for n in declared_symbols() if n not in L._SIGNATURES]
     assert not missing, missing
 

@@ -229,3 +229,40 @@ def test_pseudo_lidar_oracle_vs_reference():
         assert got.shape == g["cloud_" + name].shape and got.dtype == np.float64
         assert np.array_equal(got, g["cloud_" + name])
         assert np.all(got[:, 3] == 0.0)          # the reference's inverse_rigid_trans leaves the homogeneous row zero
+
+
+def test_preprocess_oracle_vs_pillow_golden():
+    """oracle.preprocess == the reference's transform chain run with the real Pillow (tests/golden/preprocess.npz), bit for bit; and the
+    C ABI's host-side coefficient tables (mcav_resample_coeffs) == the oracle's (Pillow's precompute_coeffs + normalize_coeffs_8bpc)."""
+    import ctypes
+    from oracle import preprocess as op
+    g = np.load(os.path.join(GOLDEN, "preprocess.npz"))
+    for name in ("down", "up", "mixed", "kitti"):
+        img, want_small, want = g["img_" + name], g["resized_" + name], g["out_" + name]
+        h, w = want_small.shape[:2]
+        assert np.array_equal(op.byte_quirk(img), img)                       # float32(v)/255*255 truncates back to v for every byte
+        assert np.array_equal(op.pil_resize_bilinear_u8(img, h, w), want_small)
+        assert np.array_equal(op.load_transform(img, h, w), want)
+    import mcav.lib as L
+    import dataloaders  # noqa: F401  (registers the signatures)
+    hnd = L.lib()
+    for in_size, out_size in ((248, 128), (33, 80), (37, 37), (1242, 640), (375, 192), (7, 2)):
+        ks, bounds, kk = op.resample_coeffs(in_size, out_size)
+        c_ks = ctypes.c_int(0)
+        cap = hnd.mcav_resample_coeffs(in_size, out_size, ctypes.byref(c_ks), None, None, 0)
+        assert c_ks.value == ks and cap == out_size * ks
+        b = np.zeros(out_size * 2, np.int32)
+        k = np.zeros(cap, np.int32)
+        assert hnd.mcav_resample_coeffs(in_size, out_size, ctypes.byref(c_ks), b.ctypes.data_as(ctypes.c_void_p), k.ctypes.data_as(ctypes.c_void_p), cap) == 0
+        assert np.array_equal(b.reshape(-1, 2), bounds) and np.array_equal(k.reshape(out_size, ks), kk)
+
+
+def test_preprocess_oracle_vs_installed_pillow():
+    """Live check against the Pillow in this environment (skipped where it is absent): random sizes, both directions."""
+    Image = pytest.importorskip("PIL.Image")
+    from oracle import preprocess as op
+    rng = np.random.RandomState(4)
+    for (h0, w0, h, w) in [(61, 97, 24, 80), (30, 30, 64, 31), (375, 1242, 192, 640), (9, 5, 9, 11)]:
+        img = rng.randint(0, 256, (h0, w0, 3)).astype(np.uint8)
+        want = np.asarray(Image.fromarray(img).resize((w, h), Image.BILINEAR))
+        assert np.array_equal(op.pil_resize_bilinear_u8(img, h, w), want)

@@ -73,3 +73,31 @@ def test_pseudo_lidar_full_size_properties():
     for k in (2, 5, 64):
         sp = PseudoLiDAR.from_matrices(g["T"], P, k).project_PL(d)
         assert torch.equal(sp, full[0::k])
+
+
+def test_image_preprocess_vs_pillow_golden():
+    """8f row 1: the transform chain on the GPU == the reference chain run with the real Pillow, bit for bit (integer resample)."""
+    from dataloaders import GpuImageTransform
+    g = np.load(os.path.join(GOLDEN, "preprocess.npz"))
+    for name in ("down", "up", "mixed", "kitti"):
+        img, want = g["img_" + name], g["out_" + name]
+        t = GpuImageTransform(want.shape[1], want.shape[2])
+        got = t(torch.from_numpy(img))                       # host uint8 -> pinned copy -> device
+        assert tuple(got.shape) == want.shape
+        assert np.array_equal(got.cpu().numpy(), want)
+    # a batch, already on the device; and the intrinsics rescale works on a copy
+    img = np.stack([g["img_kitti"], g["img_kitti"][::-1].copy()])
+    t = GpuImageTransform(48, 160)
+    got = t(torch.from_numpy(img).to(DEV))
+    assert np.array_equal(got[0].cpu().numpy(), g["out_kitti"])
+    from oracle import preprocess as op
+    assert np.array_equal(got[1].cpu().numpy(), op.load_transform(img[1], 48, 160))
+    K = torch.tensor([[721.5, 0.0, 609.6], [0.0, 721.5, 172.9], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    K2 = t.scale_intrinsics(K, 94, 311)
+    assert float(K[0, 0]) == 721.5 and abs(float(K2[0, 0]) - 721.5 * 160 / 311) < 1e-12 and abs(float(K2[1, 2]) - 172.9 * 48 / 94) < 1e-12
+    # full KITTI size against the oracle (Pillow restated): 375 x 1242 -> 192 x 640, a batch of 3
+    rng = np.random.RandomState(8)
+    big = rng.randint(0, 256, (3, 375, 1242, 3)).astype(np.uint8)
+    got = GpuImageTransform(192, 640)(torch.from_numpy(big))
+    for b in range(3):
+        assert np.array_equal(got[b].cpu().numpy(), op.load_transform(big[b], 192, 640))

@@ -71,6 +71,28 @@ def main():
                       "points_match_oracle": bool(want.shape == tuple(cloud.shape))}))
 
 
+def bench_preprocess():
+    from dataloaders import GpuImageTransform
+    from oracle import preprocess as op
+    rng = np.random.RandomState(2)
+    B, H0, W0, h, w = 36, 375, 1242, 192, 640                  # the 12 x 3 frames of one training batch, KITTI raw size
+    img = torch.from_numpy(rng.randint(0, 256, (B, H0, W0, 3)).astype(np.uint8)).cuda()
+    t = GpuImageTransform(h, w)
+    t(img)
+    ms = gpu_time(lambda: t(img))
+    t0 = time.perf_counter()
+    op_img = img[0].cpu().numpy()
+    from PIL import Image
+    for _ in range(3):
+        x = np.asarray(Image.fromarray(op_img).resize((w, h), Image.BILINEAR)).astype(np.float32) / 255.0
+        x = (x - np.asarray(op.MEAN, np.float32)) / np.asarray(op.STD, np.float32)
+    cpu = (time.perf_counter() - t0) / 3 * B
+    nbytes = B * (H0 * W0 * 3 + 3 * h * w * 4)                  # decoded bytes in, normalised floats out (the 8-bit intermediate is not counted)
+    print(json.dumps({"kernel": "mcav_image_preprocess (2 launches)", "workload": "%d decoded %dx%d RGB frames -> [%d,3,%d,%d]" % (B, H0, W0, B, h, w),
+                      "ms": round(ms, 4), "achieved_GBps": round(nbytes / ms / 1e6, 1), "peak_GBps": 8000.0, "frac": round(nbytes / ms / 1e6 / 8000.0, 4),
+                      "cpu_pillow_ms_for_the_batch_1_thread": round(cpu * 1e3, 1)}))
+
+
 def _wall(fn, n=20):
     fn()
     torch.cuda.synchronize()
@@ -83,3 +105,4 @@ def _wall(fn, n=20):
 
 if __name__ == "__main__":
     main()
+    bench_preprocess()
