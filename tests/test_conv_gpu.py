@@ -54,6 +54,10 @@ CASES = [
     (2, 12, 20, 128, 128, 3, 1, 1, 1, 2, 9),    # 32-deep K-tiles, 128x128, reflection pad
     (1, 10, 18, 64, 128, 3, 2, 1, 0, 0, 10),    # 32-deep K-tiles, 64x64, stride 2 (and its parity-class adjoint)
     (2, 6, 10, 96, 32, 3, 1, 1, 1, 2, 10),      # Cin = 96 with 32-deep K-tiles
+    (2, 6, 10, 64, 64, 3, 1, 1, 0, 1, 12),      # 32x64 tiles (16x16x4 MFMA fragments)
+    (1, 9, 11, 128, 64, 3, 2, 1, 0, 0, 12),     # 32x64 tiles, stride 2 and its parity-class adjoint
+    (2, 6, 10, 64, 64, 3, 1, 1, 1, 2, 12),      # 32x64 tiles, reflection pad (adjoint through the table kernel's border path)
+    (2, 6, 10, 64, 64, 3, 1, 1, 0, 1, 11),      # 64-deep K-tiles
     (2, 9, 35, 16, 32, 3, 1, 1, 1, 2, 0),       # halo-tile kernel: 16 -> 32, ragged tiles in both directions
     (1, 17, 66, 16, 16, 3, 1, 1, 0, 1, 0),      # halo-tile kernel with zero padding
     (2, 12, 20, 16, 16, 3, 1, 1, 1, 2, 0x200),  # the same shapes through the general kernels (bit 9)

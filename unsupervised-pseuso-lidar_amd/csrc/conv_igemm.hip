@@ -44,6 +44,7 @@ using Tile128x64k32 = Tile<128, 64, 64, 32, 32, 32>;      // 32-deep K-tiles: tw
 using Tile128x128k32 = Tile<128, 128, 64, 64, 32, 32>;
 using Tile64x64k32 = Tile<64, 64, 32, 32, 32, 32>;
 using Tile64x64k64 = Tile<64, 64, 32, 32, 32, 64>;       // 64-deep: 32 MFMAs per wavefront between barriers
+using Tile32x64k32 = Tile<32, 64, 32, 16, 16, 32>;       // short tiles for the 6x20 maps of layer4 (M = 2880): twice the workgroups
 
 // destination pixel of GEMM row m: returns false for padding rows.
 __device__ __forceinline__ bool decode_row(const IgemmParams& p, int m, int& n, int& dy, int& dx) {
@@ -1412,7 +1413,8 @@ inline int pick_tile(const mcav_igemm_desc* d, long M) {
     // measured on MI355X (tools/conv_bench.py): small output tiles with 32-deep K-tiles win at every layer shape of the step --
     // more co-resident workgroups hide the load round trips, and a 32-deep tile halves the barriers per FLOP
     if (d->mode != MCAV_G_SMALLC && ((M + 127) / 128) * ((d->n_count + 63) / 64) >= 1024) return 1;   // many rows (layer1, 48x160): 128x64 tiles, 104 vs 96 TF/s
-    if (d->mode != MCAV_G_SMALLC && d->Kp % 64 == 0 && ((M + 63) / 64) * ((d->n_count + 63) / 64) < 512) return 11;   // few workgroups: deeper K-tiles
+    // few 64x64 workgroups (layer4's 6x20 maps, M = 2880): 32x64 tiles double them -- 84 -> 104 TF/s on 512->512
+    if (d->mode != MCAV_G_SMALLC && d->Kp % 32 == 0 && ((M + 63) / 64) * ((d->n_count + 63) / 64) < 512) return 12;
     if (d->mode != MCAV_G_SMALLC && d->Kp % 32 == 0) return 10;
     const long t128x64 = ((M + 127) / 128) * ((d->n_count + 63) / 64);
     return t128x64 >= 1024 ? 1 : 2;
@@ -1430,6 +1432,7 @@ inline void tile_dims(int id, int& BM, int& BN) {
         case 9: BM = 128; BN = 128; break;
         case 10: BM = 64; BN = 64; break;
         case 11: BM = 64; BN = 64; break;
+        case 12: BM = 32; BN = 64; break;
         default: BM = 64; BN = 16; break;
     }
 }
@@ -1459,7 +1462,7 @@ inline bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
     p.no_tab = (d->tile >> 8) & 1;
     tile = pick_tile(d, Mlin) & 0xff;
     if (tile == 0) { mcav_igemm_desc dd = *d; dd.tile = 0; tile = pick_tile(&dd, Mlin); }
-    if (tile >= 8 && tile <= 10 && (d->mode == MCAV_G_SMALLC || d->Kp % 32 != 0)) return false;      // 32-deep K-tiles need Kp % 32 == 0
+    if (((tile >= 8 && tile <= 10) || tile == 12) && (d->mode == MCAV_G_SMALLC || d->Kp % 32 != 0)) return false;      // 32-deep K-tiles need Kp % 32 == 0
     if (tile == 11 && (d->mode == MCAV_G_SMALLC || d->Kp % 64 != 0)) return false;
     int BM, BN;
     tile_dims(tile, BM, BN);
@@ -1531,6 +1534,7 @@ MCAV_EXPORT int mcav_igemm(const mcav_igemm_desc* d, void* stream) {
         case 9: launch_igemm<Tile128x128k32>(p, s); break;
         case 10: launch_igemm<Tile64x64k32>(p, s); break;
         case 11: launch_igemm<Tile64x64k64>(p, s); break;
+        case 12: launch_igemm<Tile32x64k32>(p, s); break;
         default: return MCAV_E_INVALID;
     }
     return launch_status();
