@@ -10,6 +10,7 @@
 // are bank-conflict free), the loads of tile t+1 are issued before the MFMAs of tile t, one barrier per tile.
 // Fragments: one ds_read_b128 gives a lane 4 consecutive k of its row; lane-group g takes k = 4g..4g+3 of each
 // 8- (32x32x2) or 16-deep (16x16x4) sub-step, A and B permuted identically, so the products are exact fp32 fmas.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "conv_gather.h"
@@ -1588,7 +1589,8 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     p.mtiles = (p.Ktot + BM - 1) / BM;
     p.ntiles = (d->Cout + BN - 1) / BN;
     const int out_tiles = p.mtiles * p.ntiles;
-    int splits = (1024 + out_tiles - 1) / out_tiles;             // aim at ~1024 workgroups
+    static const int target_wgs = [] { const char* e = getenv("MCAV_WGRAD_TARGET_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    int splits = (target_wgs + out_tiles - 1) / out_tiles;       // aim at ~1024 workgroups (tuning knob: MCAV_WGRAD_TARGET_WGS)
     const int max_splits = (p.Mpix + 8 * KP - 1) / (8 * KP);     // but at least 8 K-tiles each
     if (splits > max_splits) splits = max_splits;
     if (splits > 512) splits = 512;
