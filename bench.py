@@ -39,7 +39,8 @@ def measured_traffic(steps_in_profile=3):
         k = json.load(open(TRAFFIC_JSON))["kernels"]
     except Exception:
         return None, None
-    conv = sum(v["hbm_bytes_per_launch"] * v["launches"] for n, v in k.items() if "igemm_kernel" in n or "wgrad_kernel" in n)
+    conv_kernels = ("igemm_kernel", "igemm_tab_kernel", "wgrad_kernel", "wgrad_tab_kernel", "conv3x3_halo", "conv3x3r_c1")
+    conv = sum(v["hbm_bytes_per_launch"] * v["launches"] for n, v in k.items() if any(c in n for c in conv_kernels))
     warp = [v["hbm_bytes_per_launch"] for n, v in k.items() if "warp_loss_kernel" in n]
     return conv / steps_in_profile, (warp[0] if warp else None)
 
