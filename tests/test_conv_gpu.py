@@ -276,7 +276,7 @@ def test_halo_kernel_fused_upsample():
         pre.backward(dy)
         spec = N.ConvSpec(torch.nn.Parameter(wt.to(DEV)), torch.nn.Parameter(bs.to(DEV)), 1, 1, N.PAD_REFLECT)
         ad = nhwc(a.detach())
-        for tile in (0, 0x200):                                                   # halo-tile kernels, then the general ones
+        for tile in (0, 0x400, 0x200):                  # merged-tap halo kernel (forward), the 9-tap halo kernel, the general kernels
             got = N.conv_fwd(spec, ad, None, up1=True, act=N.ACT_ELU, tile=tile)
             assert rel_err(nchw(got), want) < 2e-5
             da = N.conv_dgrad(spec, nhwc(dy), (2 * h, 2 * w_), n_begin=0, n_count=C, dact_aux=ad, dact=N.ACT_ELU, addend=nhwc(addend),

@@ -207,6 +207,122 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fused upsample, merged taps
+// Forward 3x3 reflection-padded conv of a nearest-2x-UPSAMPLED map (decoder conv (0,1): reference layers.py:49-58 upsample +
+// resnet_dispnet.py:88-92).  On the upsampled grid several of the nine taps of an output pixel read the SAME source pixel: for output
+// parity py the rows ky = 0 | 1,2 (py = 0) or ky = 0,1 | 2 (py = 1) coincide, likewise in x.  Per parity class the conv is therefore a
+// 2x2 conv on the low-resolution map with pre-summed filters -- 4 taps instead of 9 (2.25x fewer MFMAs), a 6 x 18 low-resolution halo
+// instead of a 10 x 34 upsampled one, and reflection padding of the upsampled grid becomes clamping of the source index.
+// A fragment is 16 same-parity pixels of one row (x = x0 + 2 r + px), so its filter set is uniform; the four fragments of a wavefront
+// (2 rows x 2 column parities) are exactly the four classes.  The sums w[ky] + w[ky'] are formed in registers from the packed filter
+// (they differ from the 9-tap result only by fp32 rounding of the weight sums).
+template <int C, int NF>
+__global__ __launch_bounds__(256) void conv3x3_halo_up_kernel(HaloParams p) {
+    constexpr int LDP = C + 4, C4 = C / 4, KC = C / 16;
+    constexpr int LH = HT_H / 2 + 2, LW = HT_W / 2 + 2;       // low-resolution halo: 6 x 18
+    __shared__ __attribute__((aligned(16))) float halo[LH * LW * LDP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = lid % p.tiles_x, ty = (lid / p.tiles_x) % p.tiles_y, n = lid / (p.tiles_x * p.tiles_y);
+    const int y0 = ty * HT_H, x0 = tx * HT_W;
+    const int Hs = p.H >> 1, Ws = p.W >> 1;
+    const int nn = lane & 15, g = lane >> 4;
+
+    // ---- merged filters: class (py, px) x merged tap (a, b); set S(parity, a): (0,0) = {0}, (0,1) = {1,2}, (1,0) = {0,1}, (1,1) = {2}
+    f32x4 wm[4][NF][4][KC];
+#pragma unroll
+    for (int h = 0; h < NF; ++h)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            f32x4 w9[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                w9[t] = *reinterpret_cast<const f32x4*>(p.w + ((size_t)(p.co0 + h * 16 + nn) * 9 + t) * C + kc * 16 + g * 4);
+#pragma unroll
+            for (int cls = 0; cls < 4; ++cls) {
+                const int py = cls >> 1, px = cls & 1;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const bool iny = py == 0 ? (a == 0 ? ky == 0 : ky >= 1) : (a == 0 ? ky <= 1 : ky == 2);
+                                const bool inx = px == 0 ? (b == 0 ? kx == 0 : kx >= 1) : (b == 0 ? kx <= 1 : kx == 2);
+                                if (iny && inx) sum += w9[ky * 3 + kx];
+                            }
+                        wm[cls][h][a * 2 + b][kc] = sum;
+                    }
+            }
+        }
+
+    // ---- low-resolution halo (source rows y0/2 - 1 .., clamped)
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.x, (unsigned)((size_t)p.B * Hs * Ws * C * 4));
+    constexpr int NLD = (LH * LW * C4 + 255) / 256;
+    f32x4 hv[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = tid + 256 * j;
+        const int pix = i / C4, c4 = i - pix * C4;
+        const int hy = pix / LW, hx = pix - hy * LW;
+        const int sy = min(max((y0 >> 1) - 1 + hy, 0), Hs - 1), sx = min(max((x0 >> 1) - 1 + hx, 0), Ws - 1);
+        hv[j] = buf_load4(rs, i < LH * LW * C4 ? (unsigned)((((n * Hs + sy) * Ws + sx) * C + c4 * 4) * 4) : OOB);
+    }
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = tid + 256 * j;
+        const int pix = i / C4, c4 = i - pix * C4;
+        if (i < LH * LW * C4) *reinterpret_cast<f32x4*>(&halo[pix * LDP + c4 * 4]) = hv[j];
+    }
+    __syncthreads();
+
+    // ---- fragment f: output row y0 + 2 wave + (f >> 1) (py = f >> 1), columns x0 + 2 r + (f & 1)
+    f32x4 acc[4][NF];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int h = 0; h < NF; ++h) acc[f][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int py = f >> 1, px = f & 1;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(&halo[((wave + py + a) * LW + r + px + b) * LDP + kc * 16 + g * 4]);
+#pragma unroll
+                    for (int h = 0; h < NF; ++h) {
+                        const f32x4 bv = wm[f][h][a * 2 + b][kc];
+                        acc[f][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[f][h], 0, 0, 0);
+                        acc[f][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[f][h], 0, 0, 0);
+                        acc[f][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[f][h], 0, 0, 0);
+                        acc[f][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[f][h], 0, 0, 0);
+                    }
+                }
+    }
+#pragma unroll
+    for (int h = 0; h < NF; ++h) {
+        const int co = p.co0 + h * 16 + nn;
+        const bool cok = co < p.n_count;
+        const float bv = (p.bias && cok) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int oy = y0 + 2 * wave + (f >> 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ox = x0 + 2 * (4 * g + e) + (f & 1);
+                if (cok && oy < p.H && ox < p.W) p.y[((size_t)(n * p.H + oy) * p.W + ox) * p.Cd + co] = act_fwd(acc[f][h][e] + bv, p.act);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 // dw[co][tap][ci] = sum_p dy[p][co] x[src(p, tap)][ci] for the same narrow layers.  Per filter tap a 16x16 (ci x co) MFMA tile
 // whose reduction runs over PIXELS: a workgroup walks over 8 x 32 pixel tiles (grid-stride), stages the input halo and the
@@ -407,6 +523,15 @@ bool mcav_try_halo(const mcav_igemm_desc* d, hipStream_t s) {
     const int grid = p.B * p.tiles_x * p.tiles_y;
 #define HALO_LAUNCH(CC, NN) \
     do { if (adj) conv3x3_halo_kernel<CC, NN, true><<<grid, 256, 0, s>>>(p); else conv3x3_halo_kernel<CC, NN, false><<<grid, 256, 0, s>>>(p); } while (0)
+    // upsampled source + reflection padding: 4 merged taps on the low-resolution map (desc.tile bit 10 keeps the 9-tap kernel)
+    if (!adj && d->up1 && d->pad_mode == MCAV_PAD_REFLECT && !(d->Hs & 1) && !(d->Ws & 1) && !((d->tile >> 10) & 1)) {
+        for (p.co0 = 0; p.co0 < d->n_count; p.co0 += 16 * nf) {
+            if (d->C1 == 16 && nf == 1) conv3x3_halo_up_kernel<16, 1><<<grid, 256, 0, s>>>(p);
+            else if (d->C1 == 16) conv3x3_halo_up_kernel<16, 2><<<grid, 256, 0, s>>>(p);
+            else conv3x3_halo_up_kernel<32, 1><<<grid, 256, 0, s>>>(p);
+        }
+        return true;
+    }
     for (p.co0 = 0; p.co0 < d->n_count; p.co0 += 16 * nf) {
         if (d->C1 == 16 && nf == 1) HALO_LAUNCH(16, 1);
         else if (d->C1 == 16) HALO_LAUNCH(16, 2);

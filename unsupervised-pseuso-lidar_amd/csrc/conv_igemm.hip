@@ -513,7 +513,10 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     __shared__ __attribute__((aligned(16))) float As[2][BM][T::LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][T::LD];
     __shared__ int s_out[BM];
-    __shared__ float s_stat[T::WAVES_M][2][BN];
+    // the BatchNorm column-sum scratch of the epilogue borrows the A panel (free once the K loop's last barrier has passed): with it the
+    // REFL kind's 64x64 tile fits 40 KB too
+    float (*const s_stat)[2][BN] = reinterpret_cast<float (*)[2][BN]>(&As[1][0][0]);
+    static_assert(sizeof(float) * BM * T::LD >= sizeof(float) * T::WAVES_M * 2 * BN, "statistics scratch fits one A buffer");
     // LDS budget: with 32-deep 64x64 tiles everything below fits 40 KB, i.e. FOUR workgroups per CU.  The offset tables are dynamic
     // shared memory sized by the launch (taps x BM x {1, 2} sources); the row coordinates are only needed while the tables are built
     // and borrow the (not yet used) A panel, except in the REFL kind, whose border wavefronts re-read them inside the loop.
