@@ -49,7 +49,7 @@ __device__ __forceinline__ void load_K(const void* K, bool f64, int b, double* K
 __global__ void pose_prepare_kernel(const float* poses, const void* K, const float* Tcw, int B, int mode, int inv,
                                     int k_f64, PrepConst* out, float* ones) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0 && ones) { ones[0] = 1.0f; ones[1] = 1.0f; }
+    if (b == 0 && ones) { ones[0] = 1.0f; ones[1] = 1.0f; reinterpret_cast<unsigned*>(ones)[2] = 0u; }      // [2]: the finalize kernel's ticket
     if (b >= B) return;
     double Kd[9], Ki[9];
     load_K(K, k_f64 != 0, b, Kd);
@@ -162,22 +162,28 @@ __global__ __launch_bounds__(256) void warp_loss_kernel(WLArgs a) {
     block_reduce_store<NACC>(acc, a.slab + ((size_t)b * nblk + blk) * SLAB, sred);
 }
 
-// One block per sample: sum the slab in fp64, turn dP into pose gradients, emit per-sample loss sums.
-__global__ __launch_bounds__(256) void warp_loss_finalize_kernel(const float* slab, int nblk, const PrepConst* pcs, const float* poses,
-                                                                 const float* upstream, unsigned flags, float* d_poses, double* sample_loss) {
+// One block per sample: sum the slab in fp64 (26 slices of the tile list per accumulator: short load chains), turn dP into pose
+// gradients, emit per-sample loss sums; the LAST block to finish (ticket in the workspace, zeroed by pose_prepare_kernel) adds the
+// samples up in index order -- one launch less than a separate total kernel, same fixed summation order.
+constexpr int FIN_PARTS = 26;       // 26 x 38 = 988 threads
+
+__global__ __launch_bounds__(1024) void warp_loss_finalize_kernel(const float* slab, int nblk, const PrepConst* pcs, const float* poses,
+                                                                  const float* upstream, unsigned flags, float* d_poses, double* sample_loss,
+                                                                  unsigned* ticket, int B, float* losses) {
     if ((flags & MCAV_WL_SKIP_IF_UNIT) && upstream[0] == 1.0f && upstream[1] == 1.0f) return;
-    __shared__ double s[6][NACC];
+    __shared__ double s[FIN_PARTS][NACC];
+    __shared__ bool last;
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (tid < 6 * NACC) {
+    if (tid < FIN_PARTS * NACC) {
         const int part = tid / NACC, k = tid - part * NACC;
         double sum = 0.0;
-        for (int blk = part; blk < nblk; blk += 6) sum += (double)slab[((size_t)b * nblk + blk) * SLAB + k];
+        for (int blk = part; blk < nblk; blk += FIN_PARTS) sum += (double)slab[((size_t)b * nblk + blk) * SLAB + k];
         s[part][k] = sum;
     }
     __syncthreads();
     if (tid < NACC) {
         double t = 0.0;
-        for (int p = 0; p < 6; ++p) t += s[p][tid];
+        for (int p = 0; p < FIN_PARTS; ++p) t += s[p][tid];
         s[0][tid] = t;
     }
     __syncthreads();
@@ -194,16 +200,17 @@ __global__ __launch_bounds__(256) void warp_loss_finalize_kernel(const float* sl
         }
         sample_loss[b * 2 + 0] = s[0][0];
         sample_loss[b * 2 + 1] = s[0][1];
-    }
-}
-
-__global__ void loss_total_kernel(const double* sample_loss, int B, const float* upstream, unsigned flags, float* losses) {
-    if ((flags & MCAV_WL_SKIP_IF_UNIT) && upstream[0] == 1.0f && upstream[1] == 1.0f) return;
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double a = 0.0, s = 0.0;
-        for (int b = 0; b < B; ++b) { a += sample_loss[b * 2]; s += sample_loss[b * 2 + 1]; }
-        losses[0] = (float)a;
-        losses[1] = (float)s;
+        __threadfence();                                        // this sample's sums are visible before the ticket is taken
+        last = atomicAdd(ticket, 1u) == (unsigned)(B - 1);
+        if (last) {
+            __threadfence();
+            double a = 0.0, sm = 0.0;
+            const volatile double* sl = sample_loss;            // written by other workgroups: read from L2
+            for (int i = 0; i < B; ++i) { a += sl[i * 2]; sm += sl[i * 2 + 1]; }
+            losses[0] = (float)a;
+            losses[1] = (float)sm;
+            *ticket = 0;
+        }
     }
 }
 
@@ -475,8 +482,7 @@ MCAV_EXPORT int mcav_warp_loss_fwd_bwd(const float* tgt, const float* ref0, cons
     a.tw[1] = term_weights ? term_weights[1] : 0.25f;
     a.tw[2] = term_weights ? term_weights[2] : 0.5f;
     warp_loss_kernel<<<pix_grid(B, H, W), 256, 0, s>>>(a);
-    warp_loss_finalize_kernel<<<B, 256, 0, s>>>(slab, l.nblk, pc, poses, up, flags, d_poses, sl);
-    loss_total_kernel<<<1, 64, 0, s>>>(sl, B, up, flags, losses);
+    warp_loss_finalize_kernel<<<B, 1024, 0, s>>>(slab, l.nblk, pc, poses, up, flags, d_poses, sl, reinterpret_cast<unsigned*>(ones) + 2, B, losses);
     return launch_status();
 }
 
