@@ -50,13 +50,13 @@ def synthetic_samples(B, H, W, rank, step=0):
     return synthetic_batch(B, H, W, seed=1234 + 1000 * rank + step)
 
 
-def build(device, lr=1e-4, seed=0):
+def build(device, lr=1e-4, seed=0, depth_layers=18):
     from models.depth.resnet_dispnet import DispResNet
     from models.pose.pose_net import PoseNet
     from mcav.optim import FusedAdam
     from losses import Losses
     torch.manual_seed(seed)
-    depth = DispResNet()
+    depth = DispResNet(depth_layers)
     pose = PoseNet()
     pose.init_weights()
     depth.to(device).train()
@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--depth-layers", type=int, default=18, help="ResNet depth of the encoder (18 = the metric's config; 50 = BASELINE.json configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--separate-passes", action="store_true", help="run the two depth passes as separate launch sets (default: stacked)")
@@ -159,7 +160,7 @@ def main():
     torch.cuda.set_device(device)
     B, H, W = args.batch, args.height, args.width
 
-    depth, pose, opt, crit = build(device)
+    depth, pose, opt, crit = build(device, depth_layers=args.depth_layers)
     mdist.broadcast_parameters(opt.arena())
     if os.environ.get("MCAV_DP_OVERLAP", "1") != "0":
         mdist.enable_overlap(opt.arena())          # N > 1: bucketed all-reduce behind the rest of backward (no-op on one rank)
@@ -191,9 +192,10 @@ def main():
     out = {"metric": "images/sec (fwd+bwd) KITTI 192x640 triplets, full training step", "value": round(value, 3), "unit": "images/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "BASELINE.json configs[1]: per-GPU batch=%d, %dx%d KITTI-shaped triplets, ResNet-18 depth encoder + 6-DoF PoseNet, "
+           "config": {"workload": "%s: per-GPU batch=%d, %dx%d KITTI-shaped triplets, ResNet-%d depth encoder + 6-DoF PoseNet, "
                                   "fp32, one step = 2x depth fwd + pose fwd + warp/L1/smooth loss + backward + Adam%s" %
-                                  (B, H, W, " + 1 RCCL all-reduce of the 63.7 MB gradient arena" if world > 1 else ""),
+                                  ("BASELINE.json configs[1]" if (B, H, W, args.depth_layers) == (12, 192, 640, 18) else "variant of BASELINE.json configs[1]",
+                                   B, H, W, args.depth_layers, " + 1 RCCL all-reduce of the gradient arena" if world > 1 else ""),
                       "global_batch": B * world, "parallelism": "dp%d" % world},
            "loss": [round(float(l.detach()), 6) for l in loss], "hipgraph": bool(getattr(make_step, "graphed", False))}
 

@@ -140,28 +140,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, uns
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
 }
 
-// Hand-counted variant for the K_FAST main loop: the load is invisible to the compiler's s_waitcnt bookkeeping (which, across
-// the loop back-edge, would drain the youngest loads too), so tile t+2 can stay in flight while tile t+1 is written to LDS.
-// The destination registers must not be touched until the matching vm_wait<N>() below.
-__device__ __forceinline__ u32x4 make_rsrc_words(const void* ptr, unsigned bytes) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
-    u32x4 r;
-    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
-    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
-    r.z = __builtin_amdgcn_readfirstlane(bytes);
-    r.w = 0x00020000u;
-    return r;
-}
-
-__device__ __forceinline__ void asm_buf_load4(f32x4& v, u32x4 rsrc, unsigned byte_off) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(byte_off), "s"(rsrc) : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void vm_wait() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
