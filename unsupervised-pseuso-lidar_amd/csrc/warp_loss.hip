@@ -13,6 +13,8 @@
 namespace mcav {
 
 constexpr int TW = 32, TH = 8, HALO = 2, LW = TW + 2 * HALO, LH = TH + 2 * HALO;
+constexpr int WL_SUB = 4, WLH = TH * WL_SUB, WL_LH = WLH + 2 * HALO;      // the fused loss kernel: 32 x 32 pixel tiles, 4 pixels per thread --
+                                                                          // the 38-value block reduction is paid once per 4 pixels
 constexpr int NACC = 38;        // loss_mam, loss_smooth, 3 x dP[12]
 constexpr int SLAB = 40;        // floats per block in the slab (padded)
 
@@ -97,14 +99,14 @@ __device__ __forceinline__ void block_reduce_store(float* acc, float* dst, float
 __global__ __launch_bounds__(256) void warp_loss_kernel(WLArgs a) {
     const float g0 = a.upstream[0], g1 = a.upstream[1];
     if ((a.flags & MCAV_WL_SKIP_IF_UNIT) && g0 == 1.0f && g1 == 1.0f) return;
-    __shared__ float sD[LH][LW + 1];
+    __shared__ float sD[WL_LH][LW + 1];
     __shared__ float sred[4][SLAB];
     const int H = a.H, W = a.W, b = blockIdx.z;
-    const int bx0 = blockIdx.x * TW, by0 = blockIdx.y * TH;
+    const int bx0 = blockIdx.x * TW, by0 = blockIdx.y * WLH;
     const size_t plane = (size_t)H * W;
     const bool in_depth = (a.flags & MCAV_WL_INPUT_DEPTH) != 0;
     const float* dt = a.disp_t + (size_t)b * plane;
-    for (int i = threadIdx.x; i < LH * LW; i += 256) {
+    for (int i = threadIdx.x; i < WL_LH * LW; i += 256) {
         const int ly = i / LW, lx = i - ly * LW;
         const int gy = by0 - HALO + ly, gx = bx0 - HALO + lx;
         float D = 0.f;
@@ -116,13 +118,15 @@ __global__ __launch_bounds__(256) void warp_loss_kernel(WLArgs a) {
     }
     __syncthreads();
 
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int x = bx0 + tx, y = by0 + ty;
+    const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;
+    const int x = bx0 + tx;
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
 
-    if (x < W && y < H) {
+    for (int sub = 0; sub < WL_SUB; ++sub) {
+        const int ty = sub * TH + ty0, y = by0 + ty;
+        if (!(x < W && y < H)) continue;
         const PrepConst& pc = a.pc[b];
         const size_t pix = (size_t)y * W + x;
         const float* tgt = a.tgt + (size_t)b * 3 * plane;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void warp_loss_kernel(WLArgs a) {
             const float cxy = 2.0f / (float)((size_t)a.B * (H - 1) * (W - 1));   // dxdy and dydx are the same field
             float gs = 0.f, ls = 0.f;
             smooth_terms([&](int dy, int dx) { return sD[cy + dy][cx + dx]; }, x, y, H, W, cxx, cyy, cxy, ls, gs);
-            acc[1] = ls;
+            acc[1] += ls;
             dDt += g1 * gs;
         }
         a.d_disp_t[(size_t)b * plane + pix] = in_depth ? dDt : dDt * (-10.0f * Dt * Dt);
@@ -481,8 +485,9 @@ MCAV_EXPORT int mcav_warp_loss_fwd_bwd(const float* tgt, const float* ref0, cons
     a.tw[0] = term_weights ? term_weights[0] : 0.25f;
     a.tw[1] = term_weights ? term_weights[1] : 0.25f;
     a.tw[2] = term_weights ? term_weights[2] : 0.5f;
-    warp_loss_kernel<<<pix_grid(B, H, W), 256, 0, s>>>(a);
-    warp_loss_finalize_kernel<<<B, 1024, 0, s>>>(slab, l.nblk, pc, poses, up, flags, d_poses, sl, reinterpret_cast<unsigned*>(ones) + 2, B, losses);
+    const dim3 wl_grid((W + TW - 1) / TW, (H + WLH - 1) / WLH, B);
+    warp_loss_kernel<<<wl_grid, 256, 0, s>>>(a);
+    warp_loss_finalize_kernel<<<B, 1024, 0, s>>>(slab, (int)(wl_grid.x * wl_grid.y), pc, poses, up, flags, d_poses, sl, reinterpret_cast<unsigned*>(ones) + 2, B, losses);
     return launch_status();
 }
 
