@@ -64,6 +64,11 @@ typedef struct mcav_igemm_desc {
     int groups;             /* 0/1 = one group.  G > 1: the batch is G equal groups (e.g. the tgt and ref0 passes of the depth net run as
                              * one launch); output tiles never straddle a group, so `stats` rows [g * mtiles/G, (g+1) * mtiles/G) belong to
                              * group g (per-pass BatchNorm statistics).  Only with the DIRECT / SMALLC gathers and pool == 0. */
+    const float* w_upmerge; /* NULL, or mcav_pack_weights_upmerge's copy of the same filter: with up1 = 1, a 3x3 stride-1 reflection-padded
+                             * DIRECT gather and a second source x2, the upsampled part of the contraction then runs as FOUR merged taps on
+                             * the low-resolution x1 instead of nine on the upsampled one (on the upsampled grid several taps of an output
+                             * pixel read the same source pixel; per output parity class their filters are pre-summed).  Same result up to
+                             * fp32 rounding of the filter sums; ignored where the launch does not qualify. */
 } mcav_igemm_desc;
 
 /* number of M-tiles (rows of `stats`) the launch will use with its chosen tile config */
@@ -102,6 +107,10 @@ int mcav_pack_weights(const float* w_oihw, int Cout, int Cin, int kh, int kw, in
  * preceding records; nblocks = that sum over all records. */
 int mcav_pack_weights_multi(const void* items_dev, int nitems, int nblocks, void* stream);
 int mcav_pack_weights_blocks(int taps, int transposed, int Np, int Kp);   /* workgroups one record needs */
+/* Merged-tap copy of a 3x3 filter for mcav_igemm_desc.w_upmerge: packed [4 parity classes (py, px)][Np][4 merged taps (a, b)][C1] with
+ * packed[cls][n][a*2+b][c] = sum of w[n][c][ky][kx] over ky in S(py, a), kx in S(px, b);  S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1},
+ * S(1,1) = {2};  c < C1 (the upsampled source's channels = the filter's first C1 input channels); rows n >= Cout are zero. */
+int mcav_pack_weights_upmerge(const float* w_oihw, int Cout, int Cin, int C1, float* packed, int Np, void* stream);
 
 /* 3x3 reflection-padded convolution with ONE output channel -- the decoder's disparity heads (reference
  * models/depth/resnet_dispnet.py:66-68 `dispconv`, layers.py:42-58 Conv3x3, applied with a sigmoid at :93-94).  HBM-bound

@@ -138,8 +138,11 @@ def test_decoder_level_fused_upsample_concat(dims):
     pre.backward(dy)
     wp, bp = torch.nn.Parameter(wt.detach().to(DEV)), torch.nn.Parameter(bs.detach().to(DEV))
     spec = N.ConvSpec(wp, bp, 1, 1, 1)
-    got = N.conv_fwd(spec, nhwc(a.detach()), nhwc(skip.detach()), up1=True, act=N.ACT_ELU)
+    got = N.conv_fwd(spec, nhwc(a.detach()), nhwc(skip.detach()), up1=True, act=N.ACT_ELU)            # merged-tap upsample path
     assert rel_err(nchw(got), want) < 2e-5
+    for tile in (0x800, 10, 0x800 | 10, 12, 1):       # the nine-tap path (bit 11), and both under 32-deep / 32-row / 128-row tiles
+        got = N.conv_fwd(spec, nhwc(a.detach()), nhwc(skip.detach()), up1=True, act=N.ACT_ELU, tile=tile)
+        assert rel_err(nchw(got), want) < 2e-5, hex(tile)
     dyd = nhwc(dy)
     N.conv_wgrad(spec, nhwc(a.detach()), dyd, x2=nhwc(skip.detach()), up1=True)
     assert rel_err(wp.grad, wt.grad) < 5e-5 and rel_err(bp.grad, bs.grad) < 5e-5

@@ -114,6 +114,10 @@ struct IgemmParams {
     int groups;
     int mtiles, ntiles;
     int no_tab;      // desc.tile bit 8: force the general kernel (A/B timing and parity of both paths)
+    const float* wm; // merged-tap filter copy (mcav_pack_weights_upmerge)
+    int Np_all;      // packed filter rows (desc.Np)
+    int bm;          // rows per tile of the chosen config (UPM row order: tiles of the four classes of one region are adjacent)
+    int upm;         // 1: rows are grouped by output parity class and the x1 part of K runs as 4 merged taps on the low-resolution source
 };
 
 __device__ __forceinline__ float act_fwd(float v, int act) {

@@ -63,6 +63,18 @@ __device__ __forceinline__ bool decode_row(const IgemmParams& p, int m, int& n, 
         return dy < p.Hd && dx < p.Wd;
     }
     if (m >= p.M) return false;
+    if (p.upm) {             // merged-tap upsample: a tile holds one output parity class (py, px); the four classes of one image region are
+                             // consecutive tiles (same XCD, same time: the skip tensor's pixels they all read stay in L2)
+        const int blk = m / p.bm, cls = blk & 3, r = (blk >> 2) * p.bm + (m - blk * p.bm);
+        if (r >= p.Mc) return false;
+        const int Hc = p.Hd >> 1, Wc = p.Wd >> 1;
+        n = r / (Hc * Wc);
+        const int q = r - n * (Hc * Wc);
+        const int y2 = q / Wc, x2 = q - y2 * Wc;
+        dy = 2 * y2 + (cls >> 1);
+        dx = 2 * x2 + (cls & 1);
+        return true;
+    }
     if (p.groups > 1) {      // group-major rows, each group padded to whole tiles
         const int grp = m / p.McP, r = m - grp * p.McP;
         if (r >= p.Mc) return false;
@@ -507,8 +519,12 @@ constexpr int TAB_TAPS = 9;
 // correlation (sy = dy + 1 - ky); a wavefront that owns rows within two pixels of the border (wave-uniform test) issues up
 // to three more loads per row -- the outputs whose reflected tap landed on this pixel -- and adds them when the tile is
 // written to LDS, one iteration later, so they cost no extra wait.
-template <class T, bool REFL>
+// TK = 2 (UPM): forward conv of cat(nearest-up2(x1), x2) with reflection padding, the x1 part as FOUR merged taps on the low-resolution
+// x1 (see mcav_igemm_desc.w_upmerge): rows are grouped by output parity class, the K loop runs 4 * C1/CK tiles from x1 with the
+// class's pre-summed filters and then the usual 9 * C2/CK tiles from x2.  Reflection on the upsampled grid = clamping the source index.
+template <class T, int TK>
 __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
+    constexpr bool REFL = TK == 1, UPM = TK == 2;
     constexpr int BM = T::BM, BN = T::BN, CKT = T::KD;
     __shared__ __attribute__((aligned(16))) float As[2][BM][T::LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][T::LD];
@@ -522,7 +538,7 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     // and borrow the (not yet used) A panel, except in the REFL kind, whose border wavefronts re-read them inside the loop.
     extern __shared__ unsigned s_dyn[];
     unsigned* const s_o1 = s_dyn;
-    unsigned* const s_o2 = s_dyn + (p.g.C2 > 0 ? p.taps * BM : 0);
+    unsigned* const s_o2 = s_dyn + (UPM ? 4 * BM : (p.g.C2 > 0 ? p.taps * BM : 0));      // UPM: 4 merged-tap rows, then the 9 taps of x2
     __shared__ int s_rows[REFL ? 3 * BM : 1];
     int* const s_rn = REFL ? s_rows : reinterpret_cast<int*>(&As[0][0][0]);
     int* const s_ry = s_rn + BM;
@@ -560,7 +576,24 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
         s_nt = nv;
     }
     __syncthreads();
-    for (int e = tid; e < p.taps * BM; e += 256) {
+    if constexpr (UPM) {
+        const int Hl = g.Hs >> 1, Wl = g.Ws >> 1;
+        for (int e = tid; e < 4 * BM; e += 256) {          // merged tap (a, b) of the row's parity class: low-resolution source, clamped
+            const int tp = e / BM, r = e - tp * BM;
+            const int n = s_rn[r], dy = s_ry[r], dx = s_rx[r];
+            const int sy = min(max((dy >> 1) - 1 + (dy & 1) + (tp >> 1), 0), Hl - 1);
+            const int sx = min(max((dx >> 1) - 1 + (dx & 1) + (tp & 1), 0), Wl - 1);
+            s_o1[e] = n >= 0 ? (unsigned)(((n * Hl + sy) * Wl + sx) * g.C1) * 4u : OOB;
+        }
+        for (int e = tid; e < 9 * BM; e += 256) {          // the skip tensor x2: nine taps, reflection padding at full resolution
+            const int tp = e / BM, r = e - tp * BM;
+            const int ky = tp / 3, kx = tp - ky * 3;
+            const int n = s_rn[r];
+            const int sy = reflect_idx(s_ry[r] + ky - 1, g.Hs), sx = reflect_idx(s_rx[r] + kx - 1, g.Ws);
+            s_o2[e] = n >= 0 ? (unsigned)(((n * g.Hs + sy) * g.Ws + sx) * g.C2) * 4u : OOB;
+        }
+    }
+    for (int e = tid; e < (UPM ? 0 : p.taps * BM); e += 256) {
         const int tp = e / BM, r = e - tp * BM;
         const int ky = tp / p.kw, kx = tp - ky * p.kw;
         const int n = s_rn[r], dy = s_ry[r], dx = s_rx[r];
@@ -591,7 +624,8 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
 
     const int ntaps = s_nt;
     const int nchunks = p.Kp / CKT;
-    const int T_total = ntaps * nchunks;
+    const int nch1 = g.C1 / CKT, nch2 = g.C2 / CKT;      // UPM: K-tiles per merged tap of x1 / per tap of x2
+    const int T_total = UPM ? 4 * nch1 + 9 * nch2 : ntaps * nchunks;
     const unsigned bytes1 = (unsigned)((size_t)g.B * (g.up1 ? (g.Hs >> 1) * (g.Ws >> 1) : g.Hs * g.Ws) * g.C1 * 4);
     const unsigned bytes2 = (unsigned)((size_t)g.B * g.Hs * g.Ws * g.C2 * 4);
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1, bytes1);
@@ -620,9 +654,31 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     }
     f32x4 ex0[REFL ? T::AROWS : 1], ex1[REFL ? T::AROWS : 1], ex2[REFL ? T::AROWS : 1];
     int ti = 0, chunk = 0;                       // the ISSUE pointer: next K-tile to load
-    int tap = __builtin_amdgcn_readfirstlane(s_tl[0]);
+    int tap = UPM ? 0 : __builtin_amdgcn_readfirstlane(s_tl[0]);
+    int seg = 0;                                 // UPM: 0 = merged taps of x1, 1 = taps of x2
     unsigned oa[T::AROWS], ob[T::AROWS];
+    unsigned boffm[UPM ? T::BVECS : 1];          // UPM: byte offsets into the merged filter copy [cls][Np][4][C1]
+    unsigned bcur[UPM ? T::BVECS : 1];           // UPM: the B offsets of the current segment
+    __amdgpu_buffer_rsrc_t rsm = rsw;
+    if constexpr (UPM) {
+        const int cls = (m0 / BM) & 3;
+        rsm = make_rsrc(p.wm, (unsigned)((size_t)4 * p.Np_all * 4 * g.C1 * 4));
+#pragma unroll
+        for (int j = 0; j < T::BVECS; ++j) {
+            const int e = tid + 256 * j, nn = e / T::LPR, cb = e % T::LPR;
+            const bool ok = nn < BN && n0 + nn < p.n_count;
+            boffm[j] = ok ? (unsigned)((((cls * p.Np_all + p.n_begin + n0 + nn) * 4) * g.C1 + cb * 4) * 4) : OOB;
+        }
+    }
     auto refresh = [&]() {
+        if constexpr (UPM) {       // one offset array for both segments: rows 0..3 of the table = merged taps of x1, rows 4..12 = taps of x2
+            const int row = seg == 0 ? tap : (tap < 9 ? 4 + tap : 4);
+#pragma unroll
+            for (int j = 0; j < T::AROWS; ++j) oa[j] = s_dyn[row * BM + r0 + T::RPP * j] + (unsigned)c4 * 16u;
+#pragma unroll
+            for (int j = 0; j < T::BVECS; ++j) bcur[j] = seg == 0 ? boffm[j] : boff[j];      // (kept in ONE register array: see issue())
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < T::AROWS; ++j) {
             oa[j] = s_o1[tap * BM + r0 + T::RPP * j] + (unsigned)c4 * 16u;      // OOB + 16 c4 is still out of range
@@ -631,6 +687,32 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     };
     refresh();
     auto issue = [&](f32x4 (&ra)[T::AROWS], f32x4 (&rb)[T::BVECS]) {
+        if constexpr (UPM) {
+            const int cb4 = chunk * CKT * 4;
+            // (the asm comments keep the two arms from being folded into per-lane selects of the buffer resources, which would turn
+            //  every load into a waterfall loop over "possibly divergent" descriptors)
+            if (__builtin_amdgcn_readfirstlane(seg) == 0) {
+                asm volatile("; x1 segment: merged taps" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < T::AROWS; ++j) ra[j] = buf_load4s(rs1, oa[j], cb4);
+                const int kb = (tap * g.C1) * 4 + cb4;
+#pragma unroll
+                for (int j = 0; j < T::BVECS; ++j) rb[j] = buf_load4s(rsm, bcur[j], kb);
+            } else {
+                asm volatile("; x2 segment: nine taps" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < T::AROWS; ++j) ra[j] = buf_load4s(rs2, oa[j], cb4);
+                const int kb = (tap * p.Kp + g.C1) * 4 + cb4;
+#pragma unroll
+                for (int j = 0; j < T::BVECS; ++j) rb[j] = buf_load4s(rsw, bcur[j], kb);
+            }
+            if (++chunk == (seg == 0 ? nch1 : nch2)) {
+                chunk = 0;
+                if (++tap == 4 && seg == 0) { seg = 1; tap = 0; }
+                refresh();
+            }
+            return;
+        }
         const int cbase = chunk * CKT;
         if (cbase < g.C1) {
 #pragma unroll
@@ -1464,6 +1546,7 @@ inline bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
     if ((long)d->B * d->Hs * d->Ws * (d->C1 > d->C2 ? d->C1 : d->C2) * 4 >= 0x7fffffffL) return false;   // 32-bit byte offsets
     if ((long)d->Np * kstride_of(d->kh * d->kw, d->Kp) * 4 >= 0x7fffffffL) return false;
     p.no_tab = (d->tile >> 8) & 1;
+    p.wm = d->w_upmerge; p.Np_all = d->Np; p.upm = 0;
     tile = pick_tile(d, Mlin) & 0xff;
     if (tile == 0) { mcav_igemm_desc dd = *d; dd.tile = 0; tile = pick_tile(&dd, Mlin); }
     if (((tile >= 8 && tile <= 10) || tile == 12) && (d->mode == MCAV_G_SMALLC || d->Kp % 32 != 0)) return false;      // 32-deep K-tiles need Kp % 32 == 0
@@ -1484,6 +1567,18 @@ inline bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
         p.Mc = 0; p.McP = 1;
         if (Mlin > 0x7fffffffL) return false;
         p.M = (int)Mlin;
+        // merged-tap upsample (see mcav_igemm_desc.w_upmerge): everything the table-driven UPM kernel needs must hold, else the plain path
+        const int ck = (tile >= 8 && tile <= 10) || tile == 12 ? 32 : (tile == 11 ? 64 : 16);
+        if (d->w_upmerge && d->mode == MCAV_G_DIRECT && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->sign == 1 && d->offset == -1 &&
+            d->pad_mode == MCAV_PAD_REFLECT && d->up1 == 1 && d->C2 > 0 && !(d->Hd & 1) && !(d->Wd & 1) && d->Hd == d->Hs && d->Wd == d->Ws &&
+            !d->pool && !d->stats && d->C1 % ck == 0 && d->C2 % ck == 0 && d->C1 + d->C2 == d->Kp && (d->C1 & 3) == 0 && !p.no_tab &&
+            (long)4 * d->Np * 4 * d->C1 * 4 < 0x7fffffffL) {
+            p.upm = 1;
+            p.bm = BM;
+            p.Mc = d->B * (d->Hd / 2) * (d->Wd / 2);
+            p.McP = round_up(p.Mc, BM);
+            p.M = 4 * p.McP;
+        }
     }
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (d->n_count + BN - 1) / BN;
@@ -1500,8 +1595,9 @@ inline void launch_igemm(const IgemmParams& p, hipStream_t s) {
     // (tall tiles put rows of many image lines into one wavefront: most wavefronts would take the border path, so they keep the general kernel)
     const bool tab_refl = p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0 && p.g.C1 == p.Kp && p.Kp % T::KD == 0 && !p.no_tab && T::AROWS <= 2;
     const size_t tab_bytes = sizeof(unsigned) * (size_t)p.taps * T::BM * (p.g.C2 > 0 ? 2 : 1);
-    if (tab) igemm_tab_kernel<T, false><<<grid, 256, tab_bytes, s>>>(p);
-    else if (tab_refl) igemm_tab_kernel<T, true><<<grid, 256, tab_bytes, s>>>(p);
+    if (p.upm) igemm_tab_kernel<T, 2><<<grid, 256, sizeof(unsigned) * 13 * T::BM, s>>>(p);
+    else if (tab) igemm_tab_kernel<T, 0><<<grid, 256, tab_bytes, s>>>(p);
+    else if (tab_refl) igemm_tab_kernel<T, 1><<<grid, 256, tab_bytes, s>>>(p);
     else if (fast_mode && c4ok) igemm_kernel<T, K_FAST><<<grid, 256, 0, s>>>(p);
     else if (p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0) igemm_kernel<T, K_REFLADJ><<<grid, 256, 0, s>>>(p);
     else igemm_kernel<T, K_GENERIC><<<grid, 256, 0, s>>>(p);
@@ -1704,6 +1800,36 @@ MCAV_EXPORT int mcav_pack_weights(const float* w_oihw, int Cout, int Cin, int kh
 }
 
 // items: device array of PackItem-compatible records {src, dst, Cout, Cin, taps, transposed, Np, Kp, Kstride, first_block}
+namespace mcav {
+__global__ __launch_bounds__(256) void pack_upmerge_kernel(const float* w, int Cout, int Cin, int C1, int Np, float* out) {
+    const size_t total = (size_t)4 * Np * 4 * C1;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C1);
+        const int mt = (int)((e / C1) % 4), n = (int)((e / ((size_t)C1 * 4)) % Np), cls = (int)(e / ((size_t)C1 * 4 * Np));
+        const int py = cls >> 1, px = cls & 1, a = mt >> 1, b = mt & 1;
+        float sum = 0.f;
+        if (n < Cout) {
+            const float* wc = w + ((size_t)n * Cin + c) * 9;
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bool iny = py == 0 ? (a == 0 ? ky == 0 : ky >= 1) : (a == 0 ? ky <= 1 : ky == 2);
+                    const bool inx = px == 0 ? (b == 0 ? kx == 0 : kx >= 1) : (b == 0 ? kx <= 1 : kx == 2);
+                    if (iny && inx) sum += wc[ky * 3 + kx];
+                }
+        }
+        out[e] = sum;
+    }
+}
+}  // namespace mcav
+
+MCAV_EXPORT int mcav_pack_weights_upmerge(const float* w_oihw, int Cout, int Cin, int C1, float* packed, int Np, void* stream) {
+    if (!w_oihw || !packed || Cout <= 0 || Cin <= 0 || C1 <= 0 || C1 > Cin || Np < Cout) return MCAV_E_INVALID;
+    const size_t total = (size_t)4 * Np * 4 * C1;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    pack_upmerge_kernel<<<blocks, 256, 0, as_stream(stream)>>>(w_oihw, Cout, Cin, C1, Np, packed);
+    return launch_status();
+}
+
 MCAV_EXPORT int mcav_pack_weights_blocks(int taps, int transposed, int Np, int Kp) {
     if (taps <= 0 || Np <= 0 || Kp <= 0) return 0;
     return pack_blocks(transposed, taps, Np, Kp);

@@ -23,7 +23,7 @@ class IgemmDesc(ctypes.Structure):
                 ("mode", c_i), ("stride", c_i), ("sign", c_i), ("offset", c_i), ("pad_mode", c_i),
                 ("y", c_p), ("Hd", c_i), ("Wd", c_i), ("Cd", c_i), ("n_begin", c_i), ("n_count", c_i), ("y_choff", c_i),
                 ("bias", c_p), ("act", c_i), ("dact_aux", c_p), ("dact", c_i), ("addend", c_p), ("pool", c_i), ("stats", c_p),
-                ("tile", c_i), ("groups", c_i)]
+                ("tile", c_i), ("groups", c_i), ("w_upmerge", c_p)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -42,6 +42,7 @@ L.register({
     "mcav_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "mcav_pack_weights_multi": (c_i, [c_p, c_i, c_i, c_p]),
     "mcav_pack_weights_blocks": (c_i, [c_i, c_i, c_i, c_i]),
+    "mcav_pack_weights_upmerge": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     "mcav_nchw_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "mcav_nhwc_to_nchw": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "mcav_bn_finalize": (c_i, [c_p, c_i, c_i, c_d, c_p, c_p, c_f, c_f] + [c_p] * 6 + [c_i, c_p, c_sz, c_p]),
@@ -204,6 +205,18 @@ class ConvSpec:
                 PACKS.repack_all(self.weight.device)       # one launch refreshes every registered copy (this one included)
         return self._fwd
 
+    def packed_upmerge(self, c1):
+        """Merged-tap copy for conv(cat(up2(x1), x2)) with reflection padding: [4 classes][Np][4 taps][c1] pre-summed filters of the
+        first c1 input channels (mcav_pack_weights_upmerge).  Small (one launch when stale); used on the forward stream only."""
+        key = self._key() + (c1,)
+        if getattr(self, "_upm", None) is None or self._key_u != key or self._upm.device != self.weight.device:
+            if getattr(self, "_upm", None) is None or self._upm.device != self.weight.device or self._upm.shape[-1] != c1:
+                self._upm = empty((4, self.np, 4, c1), self.weight)
+            L.check(L.lib().mcav_pack_weights_upmerge(P(self.weight), self.cout, self.cin, c1, P(self._upm), self.np, L.stream()),
+                    "mcav_pack_weights_upmerge")
+            self._key_u = key
+        return self._upm
+
     def packed_bwd(self):
         """Data-gradient filter: rows = input channels (padded to 16), K = output channels (padded to 16)."""
         key = self._key()
@@ -244,6 +257,9 @@ def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0, gr
     d.bias, d.act = P(spec.bias), act
     d.tile = tile
     d.groups = groups if stats else 1
+    if (up1 and x2 is not None and not stats and spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad == 1
+            and spec.pad_mode == PAD_REFLECT and C1 % 16 == 0 and not (tile >> 11) & 1):
+        d.w_upmerge = P(spec.packed_upmerge(C1))       # the upsampled part as 4 merged taps on the low-resolution x1 (tile bit 11: off)
     h = L.lib()
     slab = None
     if stats:
