@@ -111,6 +111,18 @@ int mcav_pack_weights_blocks(int taps, int transposed, int Np, int Kp);   /* wor
  * packed[cls][n][a*2+b][c] = sum of w[n][c][ky][kx] over ky in S(py, a), kx in S(px, b);  S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1},
  * S(1,1) = {2};  c < C1 (the upsampled source's channels = the filter's first C1 input channels); rows n >= Cout are zero. */
 int mcav_pack_weights_upmerge(const float* w_oihw, int Cout, int Cin, int C1, float* packed, int Np, void* stream);
+/* The ADJOINT of the same trick: the gradient of conv(reflect_pad(up2(a))) w.r.t. the low-resolution a is a 4x4 stride-2 conv of the
+ * output gradient dy (16 taps instead of 4 pixels x 9) on the EDGE-REPLICATED low-resolution domain, followed by folding the one-pixel
+ * ring back onto the border it replicates:
+ *   1. mcav_pack_weights_upmerge_adj: packed [Np >= C1][16 taps u*4+v][Kp >= Cout], V[u][v][c1][co] = sum of w[co][c1][ky][kx] over
+ *      ky in Sy(u), kx in Sy(v);  Sy(0) = {2}, Sy(1) = {1,2}, Sy(2) = {0,1}, Sy(3) = {0};
+ *   2. mcav_igemm: x1 = dy [B,H,W,Cout], mode DIRECT, kh = kw = 4, stride 2, sign 1, offset -3, zero padding, Hd = H/2 + 2, Wd = W/2 + 2,
+ *      w = that copy  ->  tmp [B, H/2 + 2, W/2 + 2, C1];
+ *   3. mcav_upsample_adj_fold: out[s,t] = sum of tmp over {s+1} u ({0} if s = 0) u ({Hl+1} if s = Hl-1) x the same in t, then
+ *      * act'(dact_aux) + addend (both optional, same layout as out [B,Hl,Wl,C]). */
+int mcav_pack_weights_upmerge_adj(const float* w_oihw, int Cout, int Cin, int C1, float* packed, int Np, int Kp, void* stream);
+int mcav_upsample_adj_fold(const float* tmp, int B, int Hl, int Wl, int C, const float* dact_aux, int dact, const float* addend, float* out,
+                           void* stream);
 
 /* 3x3 reflection-padded convolution with ONE output channel -- the decoder's disparity heads (reference
  * models/depth/resnet_dispnet.py:66-68 `dispconv`, layers.py:42-58 Conv3x3, applied with a sigmoid at :93-94).  HBM-bound

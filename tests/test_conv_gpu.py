@@ -148,6 +148,19 @@ def test_decoder_level_fused_upsample_concat(dims):
     assert rel_err(wp.grad, wt.grad) < 5e-5 and rel_err(bp.grad, bs.grad) < 5e-5
     da = N.conv_dgrad(spec, dyd, (2 * h, 2 * w_), n_begin=0, n_count=C1, pool=True)
     assert rel_err(nchw(da), a.grad) < 2e-5
+    # the same gradient as a 4x4 stride-2 conv on the edge-replicated low-resolution domain + fold (used for >= 64 channels), with epilogue
+    old_min, N.UPMERGE_ADJ_MIN_N = N.UPMERGE_ADJ_MIN_N, 16
+    try:
+        aux = torch.randn(B, C1, h, w_, generator=g)
+        add = torch.randn(B, C1, h, w_, generator=g)
+        for tile in (0, 10, 12):
+            da = N.conv_dgrad(spec, dyd, (2 * h, 2 * w_), n_begin=0, n_count=C1, pool=True, tile=tile)
+            assert rel_err(nchw(da), a.grad) < 2e-5, tile
+        da = N.conv_dgrad(spec, dyd, (2 * h, 2 * w_), n_begin=0, n_count=C1, pool=True, dact_aux=nhwc(aux), dact=N.ACT_ELU, addend=nhwc(add))
+        want_da = a.grad * torch.where(aux > 0, torch.ones_like(aux), aux + 1) + add
+        assert rel_err(nchw(da), want_da) < 2e-5
+    finally:
+        N.UPMERGE_ADJ_MIN_N = old_min
     ds = N.conv_dgrad(spec, dyd, (2 * h, 2 * w_), n_begin=C1, n_count=C2)
     assert rel_err(nchw(ds), skip.grad) < 2e-5
 

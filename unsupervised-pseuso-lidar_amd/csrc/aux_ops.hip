@@ -127,6 +127,38 @@ __global__ void colsum_final_kernel(const float* part, int nblk, int C, float* o
     out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
+// Fold of the pooled upsample adjoint (see mcav_upsample_adj_fold): tmp is the gradient on the edge-replicated low-resolution domain
+// [B][Hl+2][Wl+2][C]; the ring is added back onto the border pixels it was replicated from, then * act'(aux) + addend.
+__global__ __launch_bounds__(256) void upsample_adj_fold_kernel(const float* __restrict__ tmp, int B, int Hl, int Wl, int C4, const float* __restrict__ aux,
+                                                                int dact, const float* __restrict__ addend, float* __restrict__ out) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const size_t total = (size_t)B * Hl * Wl * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int t = (int)(r % Wl); r /= Wl;
+        const int s = (int)(r % Hl);
+        const int b = (int)(r / Hl);
+        const int ys[3] = {s + 1, s == 0 ? 0 : -1, s == Hl - 1 ? Hl + 1 : -1};
+        const int xs[3] = {t + 1, t == 0 ? 0 : -1, t == Wl - 1 ? Wl + 1 : -1};
+        v4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                if (ys[a] >= 0 && xs[e] >= 0)
+                    g += reinterpret_cast<const v4*>(tmp)[(((size_t)b * (Hl + 2) + ys[a]) * (Wl + 2) + xs[e]) * C4 + c];
+        if (aux) {
+            const v4 y = reinterpret_cast<const v4*>(aux)[i];
+            if (dact == MCAV_ACT_RELU) { g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f; g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f; }
+            else if (dact == MCAV_ACT_ELU) { g.x *= y.x > 0.f ? 1.f : y.x + 1.f; g.y *= y.y > 0.f ? 1.f : y.y + 1.f; g.z *= y.z > 0.f ? 1.f : y.z + 1.f; g.w *= y.w > 0.f ? 1.f : y.w + 1.f; }
+            else if (dact == MCAV_ACT_SIGMOID) { g.x *= y.x * (1.f - y.x); g.y *= y.y * (1.f - y.y); g.z *= y.z * (1.f - y.z); g.w *= y.w * (1.f - y.w); }
+        }
+        if (addend) g += reinterpret_cast<const v4*>(addend)[i];
+        reinterpret_cast<v4*>(out)[i] = g;
+    }
+}
+
 }  // namespace mcav
 
 using namespace mcav;
@@ -179,5 +211,14 @@ MCAV_EXPORT int mcav_colsum(const float* x, size_t n_pix, int C, float* out, int
     hipStream_t s = as_stream(stream);
     colsum_part_kernel<<<blocks, 256, 0, s>>>(x, n_pix, C, part);
     colsum_final_kernel<<<(C + 63) / 64, 64, 0, s>>>(part, blocks, C, out, accumulate);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_upsample_adj_fold(const float* tmp, int B, int Hl, int Wl, int C, const float* dact_aux, int dact, const float* addend, float* out,
+                                       void* stream) {
+    if (!tmp || !out || B <= 0 || Hl <= 0 || Wl <= 0 || C <= 0 || (C & 3)) return MCAV_E_INVALID;
+    const size_t n4 = (size_t)B * Hl * Wl * (C / 4);
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    upsample_adj_fold_kernel<<<blocks, 256, 0, as_stream(stream)>>>(tmp, B, Hl, Wl, C / 4, dact_aux, dact, addend, out);
     return launch_status();
 }

@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 //   * the accumulators never leave their registers (no conditional around the MFMAs).
 // fp32 MFMA and the VALU share the SIMD's FMA datapath on gfx950 (equal peak rates): an address instruction in the loop costs
 // MFMA time, and the previous loop spent about a third of its issue slots on them.
-constexpr int TAB_TAPS = 9;
+constexpr int TAB_TAPS = 16;     // 3x3 filters, and the 4x4 stride-2 form of the pooled upsample adjoint
 
 // REFL = the adjoint of the 3x3 reflection-padded conv (decoder dgrad): away from the image border it is the plain
 // correlation (sy = dy + 1 - ky); a wavefront that owns rows within two pixels of the border (wave-uniform test) issues up
@@ -1827,6 +1827,37 @@ MCAV_EXPORT int mcav_pack_weights_upmerge(const float* w_oihw, int Cout, int Cin
     const size_t total = (size_t)4 * Np * 4 * C1;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     pack_upmerge_kernel<<<blocks, 256, 0, as_stream(stream)>>>(w_oihw, Cout, Cin, C1, Np, packed);
+    return launch_status();
+}
+
+namespace mcav {
+// Adjoint counterpart: packed [n = c1][16 taps (u, v)][k = co], V[u][v][c1][co] = sum of w[co][c1][ky][kx] over ky in Sy(u), kx in Sy(v);
+// Sy(0) = {2}, Sy(1) = {1,2}, Sy(2) = {0,1}, Sy(3) = {0}.
+__global__ __launch_bounds__(256) void pack_upmerge_adj_kernel(const float* w, int Cout, int Cin, int C1, int Np, int Kp, float* out) {
+    const size_t total = (size_t)Np * 16 * Kp;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int k = (int)(e % Kp), tap = (int)((e / Kp) % 16), n = (int)(e / ((size_t)Kp * 16));
+        const int u = tap >> 2, v = tap & 3;
+        float sum = 0.f;
+        if (n < C1 && k < Cout) {
+            const float* wc = w + ((size_t)k * Cin + n) * 9;
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bool iny = u == 0 ? ky == 2 : (u == 1 ? ky >= 1 : (u == 2 ? ky <= 1 : ky == 0));
+                    const bool inx = v == 0 ? kx == 2 : (v == 1 ? kx >= 1 : (v == 2 ? kx <= 1 : kx == 0));
+                    if (iny && inx) sum += wc[ky * 3 + kx];
+                }
+        }
+        out[e] = sum;
+    }
+}
+}  // namespace mcav
+
+MCAV_EXPORT int mcav_pack_weights_upmerge_adj(const float* w_oihw, int Cout, int Cin, int C1, float* packed, int Np, int Kp, void* stream) {
+    if (!w_oihw || !packed || Cout <= 0 || Cin <= 0 || C1 <= 0 || C1 > Cin || Np < C1 || Kp < Cout) return MCAV_E_INVALID;
+    const size_t total = (size_t)Np * 16 * Kp;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    pack_upmerge_adj_kernel<<<blocks, 256, 0, as_stream(stream)>>>(w_oihw, Cout, Cin, C1, Np, Kp, packed);
     return launch_status();
 }
 

@@ -43,6 +43,8 @@ L.register({
     "mcav_pack_weights_multi": (c_i, [c_p, c_i, c_i, c_p]),
     "mcav_pack_weights_blocks": (c_i, [c_i, c_i, c_i, c_i]),
     "mcav_pack_weights_upmerge": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "mcav_pack_weights_upmerge_adj": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "mcav_upsample_adj_fold": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
     "mcav_nchw_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "mcav_nhwc_to_nchw": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "mcav_bn_finalize": (c_i, [c_p, c_i, c_i, c_d, c_p, c_p, c_f, c_f] + [c_p] * 6 + [c_i, c_p, c_sz, c_p]),
@@ -217,6 +219,18 @@ class ConvSpec:
             self._key_u = key
         return self._upm
 
+    def packed_upmerge_adj(self, c1):
+        """[up16(c1)][16 taps][up16(cout)]: the 4x4 stride-2 filter of the pooled upsample adjoint (mcav_pack_weights_upmerge_adj)."""
+        key = self._key() + (c1,)
+        if getattr(self, "_upa", None) is None or self._key_ua != key or self._upa.device != self.weight.device:
+            npd, kpd = up16(c1), up16(self.cout)
+            if getattr(self, "_upa", None) is None or self._upa.device != self.weight.device or self._upa.shape[0] != npd:
+                self._upa = empty((npd, 16 * kpd), self.weight)
+            L.check(L.lib().mcav_pack_weights_upmerge_adj(P(self.weight), self.cout, self.cin, c1, P(self._upa), npd, kpd, L.stream()),
+                    "mcav_pack_weights_upmerge_adj")
+            self._key_ua = key
+        return self._upa
+
     def packed_bwd(self):
         """Data-gradient filter: rows = input channels (padded to 16), K = output channels (padded to 16)."""
         key = self._key()
@@ -283,6 +297,10 @@ def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=N
     Hs, Ws = in_shape
     if n_count is None:
         n_count = spec.cin
+    if (pool and n_begin == 0 and out is None and spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad == 1
+            and spec.pad_mode == PAD_REFLECT and n_count % 16 == 0 and n_count >= UPMERGE_ADJ_MIN_N and Cout == up16(spec.cout)
+            and Cout % 32 == 0 and Hs % 2 == 0 and Ws % 2 == 0 and not (tile >> 12) & 1):
+        return _dgrad_upsample_merged(spec, dy, (Hs, Ws), n_count, dact_aux, dact, addend, tile)
     wb = spec.packed_bwd()
     y = out if out is not None else empty((B, Hs // 2 if pool else Hs, Ws // 2 if pool else Ws, n_count), dy)
     d = IgemmDesc()
@@ -307,6 +325,32 @@ def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=N
     with _Timed("dgrad", 2.0 * B * Hd * Wd * spec.cout * n_count * spec.kh * spec.kw,
                 "M=%d N=%d K=%dx%d s%d mode%d pool%d %dx%d" % (B * Hs * Ws, n_count, Cout, spec.kh * spec.kw, spec.stride, d.mode, int(pool), Hs, Ws)):
         L.check(L.lib().mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(dgrad)")
+    return y
+
+
+UPMERGE_ADJ_MIN_N = 64       # narrower outputs: the halo-tile adjoint kernel is faster
+
+
+def _dgrad_upsample_merged(spec, dy, in_shape, c1, dact_aux, dact, addend, tile):
+    """d loss / d a for conv(reflect_pad(up2(a)) ...): a 4x4 stride-2 conv of dy on the edge-replicated low-resolution domain (16 taps per
+    low-resolution pixel instead of 4 pixels x 9 taps), then the ring folded back onto the border (see mcav_conv.h)."""
+    B, Hd, Wd, Cout = dy.shape
+    Hl, Wl = in_shape[0] // 2, in_shape[1] // 2
+    tmp = empty((B, Hl + 2, Wl + 2, c1), dy)
+    d = IgemmDesc()
+    d.x1, d.x2 = P(dy), None
+    d.B, d.Hs, d.Ws, d.C1, d.C2, d.up1 = B, Hd, Wd, Cout, 0, 0
+    d.w = P(spec.packed_upmerge_adj(c1))
+    d.kh, d.kw, d.Np, d.Kp = 4, 4, up16(c1), up16(spec.cout)
+    d.mode, d.stride, d.sign, d.offset, d.pad_mode = G_DIRECT, 2, 1, -3, PAD_ZERO
+    d.y, d.Hd, d.Wd, d.Cd, d.n_begin, d.n_count, d.y_choff = P(tmp), Hl + 2, Wl + 2, c1, 0, c1, 0
+    d.bias, d.act = None, ACT_NONE
+    d.tile = tile & 0xff
+    with _Timed("dgrad", 2.0 * B * Hd * Wd * spec.cout * c1 * 9,
+                "M=%d N=%d K=%dx9 s1 mode2 pool1 (merged 4x4/s2) %dx%d" % (B * Hd * Wd, c1, Cout, Hd, Wd)):
+        L.check(L.lib().mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(dgrad, merged upsample)")
+        y = empty((B, Hl, Wl, c1), dy)
+        L.check(L.lib().mcav_upsample_adj_fold(P(tmp), B, Hl, Wl, c1, P(dact_aux), dact, P(addend), P(y), L.stream()), "mcav_upsample_adj_fold")
     return y
 
 
