@@ -328,7 +328,8 @@ def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=N
     return y
 
 
-UPMERGE_ADJ_MIN_N = 64       # narrower outputs: the halo-tile adjoint kernel is faster
+import os as _os
+UPMERGE_ADJ_MIN_N = int(_os.environ.get("MCAV_UPMERGE_ADJ_MIN_N", "32"))       # narrower outputs: the halo-tile adjoint kernel is faster
 
 
 def _dgrad_upsample_merged(spec, dy, in_shape, c1, dact_aux, dact, addend, tile):
