@@ -283,14 +283,14 @@ def test_halo_kernel_fused_upsample():
     for (B, h, w_, C, Cout) in [(2, 7, 19, 16, 16), (1, 1, 1, 16, 32), (2, 4, 16, 32, 16), (1, 5, 40, 32, 32)]:
         pre_a = torch.randn(B, C, h, w_, generator=g).requires_grad_()
         a = F.elu(pre_a)
-        wt = torch.randn(Cout, C, 3, 3, generator=g) * 0.1
-        bs = 0.1 * torch.randn(Cout, generator=g)
+        wt = (torch.randn(Cout, C, 3, 3, generator=g) * 0.1).requires_grad_()
+        bs = (0.1 * torch.randn(Cout, generator=g)).requires_grad_()
         pre = F.conv2d(F.pad(F.interpolate(a, scale_factor=2, mode="nearest"), (1, 1, 1, 1), mode="reflect"), wt, bs)
         want = F.elu(pre)
         dy = torch.randn(pre.shape, generator=g)
         addend = torch.randn(B, C, h, w_, generator=g)
         pre.backward(dy)
-        spec = N.ConvSpec(torch.nn.Parameter(wt.to(DEV)), torch.nn.Parameter(bs.to(DEV)), 1, 1, N.PAD_REFLECT)
+        spec = N.ConvSpec(torch.nn.Parameter(wt.detach().to(DEV)), torch.nn.Parameter(bs.detach().to(DEV)), 1, 1, N.PAD_REFLECT)
         ad = nhwc(a.detach())
         for tile in (0, 0x400, 0x200):                  # merged-tap halo kernel (forward), the 9-tap halo kernel, the general kernels
             got = N.conv_fwd(spec, ad, None, up1=True, act=N.ACT_ELU, tile=tile)
@@ -298,6 +298,10 @@ def test_halo_kernel_fused_upsample():
             da = N.conv_dgrad(spec, nhwc(dy), (2 * h, 2 * w_), n_begin=0, n_count=C, dact_aux=ad, dact=N.ACT_ELU, addend=nhwc(addend),
                               pool=True, tile=tile)
             assert rel_err(nchw(da), pre_a.grad + addend) < 2e-5
+            spec.weight.grad = None                       # weight / bias gradient: merged-tap halo kernel, plain halo kernel, general kernel
+            spec.bias.grad = None
+            N.conv_wgrad(spec, ad, nhwc(dy), up1=True, tile=tile)
+            assert rel_err(spec.weight.grad, wt.grad) < 5e-5 and rel_err(spec.bias.grad, bs.grad) < 5e-5, hex(tile)
 
 
 def test_multi_pack_matches_single_pack():

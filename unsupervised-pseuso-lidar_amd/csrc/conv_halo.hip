@@ -493,6 +493,181 @@ __global__ __launch_bounds__(256) void conv3x3_halo_wgrad_kernel(HaloWgradParams
     }
 }
 
+// Weight gradient of the conv on the nearest-2x-UPSAMPLED map (decoder conv (0,1)) with the same merged taps as conv3x3_halo_up_kernel:
+// per parity class 4 taps on the low-resolution source (2.25x fewer MFMAs); k-steps are class-pure so every MFMA belongs to one
+// (class, merged tap) accumulator; at the end the 16 accumulators are un-merged into the 9 filter taps and reduced as usual.
+template <int C, int NF>
+__global__ __launch_bounds__(256) void conv3x3_halo_wgrad_up_kernel(HaloWgradParams p) {
+    constexpr int LDX = C == 16 ? 16 : 48;          // floats per halo pixel (bank-disjoint pixel groups, see above)
+    constexpr int LDY = NF == 1 ? 16 : 48;          // floats per dy pixel
+    constexpr int C4 = C / 4, MFR = C / 16, N4 = NF * 4;
+    constexpr int LH = HT_H / 2 + 2, LW = HT_W / 2 + 2;       // low-resolution halo of the upsampled source: 6 x 18
+    constexpr int XS = LH * LW * LDX, YS = HT_H * HT_W * LDY;
+    __shared__ __attribute__((aligned(16))) float lds[XS + YS];
+    float* const xs = lds;
+    float* const ys = lds + XS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kk = lane >> 4;
+
+    f32x4 accm[4][4][MFR][NF];                               // [parity class][merged tap]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int a = 0; a < MFR; ++a)
+#pragma unroll
+                for (int b = 0; b < NF; ++b) accm[c][t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    const int Hs = p.up ? p.H >> 1 : p.H, Ws = p.up ? p.W >> 1 : p.W;
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(p.x, (unsigned)((size_t)p.B * Hs * Ws * C * 4));
+    const __amdgpu_buffer_rsrc_t rsy = make_rsrc(p.dy, (unsigned)((size_t)p.B * p.H * p.W * p.Cdy * 4));
+    constexpr int NLX = (LH * LW * C4 + 255) / 256;
+    constexpr int NLY = (HT_H * HT_W * N4 + 255) / 256;
+
+    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
+        const int y0 = ty * HT_H, x0 = tx * HT_W;
+        f32x4 hv[NLX], dv[NLY];
+#pragma unroll
+        for (int j = 0; j < NLX; ++j) {      // low-resolution source, clamped (= reflection padding of the upsampled grid)
+            const int i = tid + 256 * j;
+            const int pix = i / C4, c4 = i - pix * C4;
+            const int hy = pix / LW, hx = pix - hy * LW;
+            const int sy = min(max((y0 >> 1) - 1 + hy, 0), Hs - 1), sx = min(max((x0 >> 1) - 1 + hx, 0), Ws - 1);
+            hv[j] = buf_load4(rsx, i < LH * LW * C4 ? (unsigned)((((n * Hs + sy) * Ws + sx) * C + c4 * 4) * 4) : OOB);
+        }
+#pragma unroll
+        for (int j = 0; j < NLY; ++j) {      // dy tile; pixels past the image (ragged tiles) and channels past Cout read as zero
+            const int i = tid + 256 * j;
+            const int pix = i / N4, c4 = i - pix * N4;
+            const int ly = pix / HT_W, lx = pix - ly * HT_W;
+            const bool ok = i < HT_H * HT_W * N4 && y0 + ly < p.H && x0 + lx < p.W && c4 * 4 < p.Cout;
+            dv[j] = buf_load4(rsy, ok ? (unsigned)((((n * p.H + y0 + ly) * p.W + x0 + lx) * p.Cdy + p.dy_choff + c4 * 4) * 4) : OOB);
+        }
+        __syncthreads();                     // the previous tile's MFMAs have read the panels
+#pragma unroll
+        for (int j = 0; j < NLX; ++j) {
+            const int i = tid + 256 * j;
+            const int pix = i / C4, c4 = i - pix * C4;
+            if (i < LH * LW * C4) *reinterpret_cast<f32x4*>(&xs[pix * LDX + c4 * 4]) = hv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NLY; ++j) {
+            const int i = tid + 256 * j;
+            const int pix = i / N4, c4 = i - pix * N4;
+            if (i < HT_H * HT_W * N4) {
+                *reinterpret_cast<f32x4*>(&ys[pix * LDY + c4 * 4]) = dv[j];
+                if (p.want_bias) bsum += dv[j];          // 256 % N4 == 0: a thread always holds the same 4 output channels
+            }
+        }
+        __syncthreads();
+        // this wavefront's 64 pixels: rows 2 wave + py; a k-step = 4 SAME-PARITY pixels x = 2 (4 q + kk) + px, so that its MFMA
+        // belongs to one (parity class, merged tap) accumulator; source of merged tap (a, b): low-resolution (wave + py + a, 4 q + kk + px + b)
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const int py = s4 >> 3, px = (s4 >> 2) & 1, q = s4 & 3;
+            const int ly = 2 * wave + py, lx = 2 * (4 * q + kk) + px;
+            float bval[NF];
+#pragma unroll
+            for (int b = 0; b < NF; ++b) bval[b] = ys[(ly * HT_W + lx) * LDY + b * 16 + i16];
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                    for (int a = 0; a < MFR; ++a) {
+                        const float av = xs[((wave + py + ta) * LW + 4 * q + kk + px + tb) * LDX + a * 16 + i16];
+#pragma unroll
+                        for (int b = 0; b < NF; ++b)
+                            accm[py * 2 + px][ta * 2 + tb][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bval[b], accm[py * 2 + px][ta * 2 + tb][a][b], 0, 0, 0);
+                    }
+        }
+    }
+
+    // ---- un-merge: the gradient of filter tap (ky, kx) is the sum over the four classes of the merged tap it belongs to there
+    f32x4 acc[9][MFR][NF];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int a = 0; a < MFR; ++a)
+#pragma unroll
+                for (int b = 0; b < NF; ++b) {
+                    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int py = 0; py < 2; ++py)
+#pragma unroll
+                        for (int px = 0; px < 2; ++px) {
+                            const int ta = py == 0 ? (ky == 0 ? 0 : 1) : (ky == 2 ? 1 : 0);
+                            const int tb = px == 0 ? (kx == 0 ? 0 : 1) : (kx == 2 ? 1 : 0);
+                            sum += accm[py * 2 + px][ta * 2 + tb][a][b];
+                        }
+                    acc[ky * 3 + kx][a][b] = sum;
+                }
+
+    // ---- sum the 4 wavefronts through LDS (two rounds), then one slab partial per workgroup
+    __syncthreads();
+    constexpr int NACC = 9 * MFR * NF;                     // f32x4 accumulators per lane
+    f32x4* const red = reinterpret_cast<f32x4*>(lds);       // [2][NACC][64]
+    static_assert((size_t)2 * NACC * 64 * 16 <= sizeof(float) * (XS + YS), "reduction buffer fits the panels");
+    auto dump = [&](int slot) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int a = 0; a < MFR; ++a)
+#pragma unroll
+                for (int b = 0; b < NF; ++b) red[(slot * NACC + (t * MFR + a) * NF + b) * 64 + lane] = acc[t][a][b];
+    };
+    auto absorb = [&](int slot) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int a = 0; a < MFR; ++a)
+#pragma unroll
+                for (int b = 0; b < NF; ++b) acc[t][a][b] += red[(slot * NACC + (t * MFR + a) * NF + b) * 64 + lane];
+    };
+    if (wave >= 2) dump(wave - 2);
+    __syncthreads();
+    if (wave < 2) absorb(wave);
+    __syncthreads();
+    if (wave == 1) dump(0);
+    __syncthreads();
+    float* const slab = p.slab + (size_t)blockIdx.x * (p.Ktot + 1) * p.slabN;
+    if (wave == 0) {
+        absorb(0);
+        // D layout: row (input channel) = 4 (lane >> 4) + e, column (output channel) = lane & 15
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int a = 0; a < MFR; ++a)
+#pragma unroll
+                for (int b = 0; b < NF; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ci = a * 16 + 4 * kk + e, co = b * 16 + i16;
+                        if (co < p.slabN) slab[(size_t)(t * C + ci) * p.slabN + co] = acc[t][a][b][e];
+                    }
+    }
+    if (p.want_bias) {                                      // column sums of dy: threads with the same channel group, fixed order
+        __syncthreads();
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < N4) {
+            f32x4 tsum = {0.f, 0.f, 0.f, 0.f};
+            for (int k = tid; k < 256; k += N4) tsum += red[k];
+            const int co = tid * 4;
+            float* o = slab + (size_t)p.Ktot * p.slabN + co;
+            if (co + 0 < p.slabN) o[0] = tsum.x;
+            if (co + 1 < p.slabN) o[1] = tsum.y;
+            if (co + 2 < p.slabN) o[2] = tsum.z;
+            if (co + 3 < p.slabN) o[3] = tsum.w;
+        }
+    }
+}
+
 }  // namespace mcav
 
 using namespace mcav;
@@ -560,7 +735,9 @@ void mcav_halo_wgrad_launch(const mcav_wgrad_desc* d, float* slab, int slabN, in
     p.dy = d->dy; p.Cdy = d->Cdy; p.dy_choff = d->dy_choff; p.Cout = d->Cout;
     p.slab = slab; p.slabN = slabN; p.Ktot = 9 * d->Kp; p.want_bias = d->dbias != nullptr;
     p.tiles_x = (p.W + HT_W - 1) / HT_W; p.tiles_y = (p.H + HT_H - 1) / HT_H; p.tiles = p.B * p.tiles_x * p.tiles_y;
-    if (d->C1 == 16 && d->Cout <= 16) conv3x3_halo_wgrad_kernel<16, 1><<<splits, 256, 0, s>>>(p);
+    if (p.up && p.pad_mode == MCAV_PAD_REFLECT && !(p.H & 1) && !(p.W & 1) && d->C1 == 16 && d->Cout <= 16 && !((d->tile >> 10) & 1))
+        conv3x3_halo_wgrad_up_kernel<16, 1><<<splits, 256, 0, s>>>(p);
+    else if (d->C1 == 16 && d->Cout <= 16) conv3x3_halo_wgrad_kernel<16, 1><<<splits, 256, 0, s>>>(p);
     else if (d->C1 == 16) conv3x3_halo_wgrad_kernel<16, 2><<<splits, 256, 0, s>>>(p);
     else conv3x3_halo_wgrad_kernel<32, 1><<<splits, 256, 0, s>>>(p);
 }
