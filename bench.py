@@ -41,8 +41,12 @@ def measured_traffic(steps_in_profile=3):
         return None, None
     conv_kernels = ("igemm_kernel", "igemm_tab_kernel", "wgrad_kernel", "wgrad_tab_kernel", "conv3x3_halo", "conv3x3r_c1")
     conv = sum(v["hbm_bytes_per_launch"] * v["launches"] for n, v in k.items() if any(c in n for c in conv_kernels))
-    warp = [v["hbm_bytes_per_launch"] for n, v in k.items() if "warp_loss_kernel" in n]
-    return conv / steps_in_profile, (warp[0] if warp else None)
+    # The fused loss kernel is also launched as a device-side no-op (backward with unit upstream): take its largest launch.  Its loads are
+    # 4 B per lane, an access width the guide leaves uncalibrated: undoubled, FETCH_SIZE equals the compulsory read bytes (11 planes) within
+    # 1 %, so it is NOT doubled here (doubling would claim that every input plane is fetched twice).
+    warp = [(v.get("fetch_size_kb_max_launch_raw", 0.0) + v.get("write_size_kb_max_launch_raw", 0.0)) * 1024.0
+            for n, v in k.items() if "warp_loss_kernel" in n]
+    return conv / steps_in_profile, (warp[0] if warp and warp[0] > 0 else None)
 
 
 def synthetic_samples(B, H, W, rank, step=0):

@@ -15,24 +15,28 @@ import sys
 
 
 def load(d, name):
-    agg = collections.defaultdict(lambda: [0.0, 0])
+    """kernel -> list of per-launch counter values, in launch order (a launch's rows -- one per XCD / dimension -- are summed)."""
+    per = collections.defaultdict(lambda: collections.OrderedDict())
     for f in glob.glob(d + "/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == name:
-                a = agg[r["Kernel_Name"]]
-                a[0] += float(r["Counter_Value"])
-                a[1] += 1
-    return agg
+                disp = per[r["Kernel_Name"]]
+                disp[r["Dispatch_Id"]] = disp.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    return {k: list(v.values()) for k, v in per.items()}
 
 
 def main():
     fe, wr = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     out = {}
-    for k, (v, n) in fe.items():
-        w, wn = wr.get(k, [0.0, 1])
-        out[k] = {"launches": n, "fetch_size_kb_per_launch_raw": v / n, "write_size_kb_per_launch_raw": w / max(1, wn),
-                  "hbm_bytes_per_launch": (2.0 * v / n + w / max(1, wn)) * 1024.0}
-    json.dump({"note": "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)",
+    for k, fv in fe.items():
+        wv = wr.get(k, [])
+        n = len(fv)
+        pairs = [(2.0 * fv[i] + (wv[i] if i < len(wv) else 0.0)) * 1024.0 for i in range(n)]      # the two passes launch in the same order
+        out[k] = {"launches": n, "fetch_size_kb_per_launch_raw": sum(fv) / n, "write_size_kb_per_launch_raw": sum(wv) / max(1, len(wv)),
+                  "hbm_bytes_per_launch": sum(pairs) / n, "hbm_bytes_max_launch": max(pairs),
+                  "fetch_size_kb_max_launch_raw": max(fv), "write_size_kb_max_launch_raw": max(wv) if wv else 0.0}
+    json.dump({"note": "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 averaged over launches (gfx950: FETCH_SIZE tallies 128-B "
+                       "requests at 64 B); hbm_bytes_max_launch = the largest launch (kernels that are also launched as device-side no-ops)",
                "kernels": out}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 
 
