@@ -116,3 +116,49 @@ def test_trainer_runs_synthetic_epoch():
     t = Trainer(cfg)
     t.train()
     assert t.step == 4 and torch.isfinite(sum(t.loss)).item()
+
+
+def test_full_size_step_is_bit_reproducible_and_pair_equals_separate():
+    """BASELINE configs[1] size (batch 12, 192x640), properties that need no oracle:
+    (1) the whole step -- three HIP streams, slab reductions, no float atomics -- gives bit-identical gradients when repeated from the same
+        state (a missing stream dependency would show up here as run-to-run differences);
+    (2) the stacked (tgt, ref0) depth passes equal two separate passes: the same loss and gradients to fp32 rounding in train mode (per-pass
+        BatchNorm statistics), the same depth maps within the 1e-3 bound in eval mode."""
+    from losses import Losses
+    from mcav.optim import FusedAdam
+    from mcav.streams import Branch
+    from oracle.step import synthetic_batch
+    hip_d, hip_p, _, _ = build_pair()
+    s = synthetic_batch(12, 192, 640, seed=9)
+    tgt, refs, K = s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], s["intrinsics"].to(DEV)
+    opt = FusedAdam(list(hip_d.parameters()) + list(hip_p.parameters()), 1e-4)
+    state = {k: v.clone() for k, v in hip_d.state_dict().items()}
+    branch = Branch()
+
+    def step(pair=True):
+        hip_d.load_state_dict(state)                       # same BatchNorm running statistics every time
+        opt.zero_grad()
+        poses = branch.fork(hip_p, tgt, refs)
+        disps = list(hip_d.forward_pair(tgt, refs[0])) if pair else [hip_d(tgt), hip_d(refs[0])]
+        poses = branch.join(poses)
+        loss = Losses().forward(tgt, refs, disps, poses, K, None)
+        sum(loss).backward()
+        torch.cuda.synchronize()
+        return [float(l.detach()) for l in loss], opt.arena().gflat.clone(), [d[0].detach().clone() for d in disps]
+
+    l1, g1, d1 = step()
+    l2, g2, d2 = step()
+    assert l1 == l2 and torch.equal(g1, g2) and all(torch.equal(a, b) for a, b in zip(d1, d2))
+    assert float(g1.abs().max()) > 0 and torch.isfinite(g1).all()
+    l3, g3, d3 = step(pair=False)
+    for a, b in zip(l1, l3):
+        assert abs(a - b) <= 1e-5 * abs(b)
+    assert float((g1 - g3).norm() / g3.norm()) < 1e-3
+    hip_d.eval()
+    with torch.no_grad():
+        pa, pb = hip_d.forward_pair(tgt, refs[0])
+        sa, sb = hip_d(tgt), hip_d(refs[0])
+    for stacked, single in ((pa[0], sa[0]), (pb[0], sb[0])):      # (not bit-equal: twice the rows select other tile shapes / summation orders)
+        ds, dn = 1 / (10 * stacked + 0.01), 1 / (10 * single + 0.01)
+        assert float(((ds - dn).abs() / dn).max()) < 1e-3 and float(((ds - dn).abs() / dn).mean()) < 1e-5
+    hip_d.train()
