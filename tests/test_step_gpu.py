@@ -162,3 +162,18 @@ def test_full_size_step_is_bit_reproducible_and_pair_equals_separate():
         ds, dn = 1 / (10 * stacked + 0.01), 1 / (10 * single + 0.01)
         assert float(((ds - dn).abs() / dn).max()) < 1e-3 and float(((ds - dn).abs() / dn).mean()) < 1e-5
     hip_d.train()
+
+
+def test_trainer_validate_runs():
+    """The validation loop of the reference (trainer.py:315-337, never called there and broken in compute_errors) runs on the GPU metrics kernel."""
+    import yaml
+    import os
+    from conftest import PKG
+    from trainer import Trainer
+    cfg = yaml.full_load(open(os.path.join(PKG, "configs", "basic_config.yaml")))
+    cfg["datasets"]["augmentation"].update(image_width=128, image_height=64)
+    cfg["datasets"]["synthetic_length"] = 20       # validation split: 20 %
+    cfg["action"].update(batch_size=2, verbose=False, save_checkpoints=False)
+    t = Trainer(cfg)
+    acc = t.validate()
+    assert acc is not None and set(("abs_rel", "rms", "d1", "silog", "count")) <= set(acc)
