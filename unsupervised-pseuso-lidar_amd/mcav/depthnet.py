@@ -128,6 +128,7 @@ def encoder_forward(net, x4, train, groups=1):
         blocks.append(stage_sv)
         feats.append(x)
     sv["blocks"], sv["feats"] = blocks, feats
+    N.flush_bn_counters()
     return feats, sv
 
 

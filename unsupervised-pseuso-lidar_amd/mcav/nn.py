@@ -495,8 +495,24 @@ def bn_train_coeffs(bn, slab, count, groups=1):
     L.check(h.mcav_bn_finalize(P(slab), mtiles, C, float(count), P(bn.weight), P(bn.bias), bn.eps, bn.momentum,
                                P(bn.running_mean), P(bn.running_var), P(st.scale), P(st.shift), P(st.mean), P(st.invstd), groups,
                                P(ws), ws.numel() if ws is not None else 0, L.stream()), "mcav_bn_finalize")
-    bn.num_batches_tracked += groups
+    _NBT_PENDING.append((bn.num_batches_tracked, groups))      # one fused add per forward pass instead of one tiny launch per layer
+    if len(_NBT_PENDING) >= 256:
+        flush_bn_counters()
     return st
+
+
+_NBT_PENDING = []
+
+
+def flush_bn_counters():
+    """num_batches_tracked += groups for every train-mode BatchNorm since the last flush (the networks call this at the end of forward)."""
+    if _NBT_PENDING:
+        by_inc = {}
+        for t, inc in _NBT_PENDING:
+            by_inc.setdefault(inc, []).append(t)
+        for inc, ts in by_inc.items():
+            torch._foreach_add_(ts, inc)
+        _NBT_PENDING.clear()
 
 
 def bn_eval_coeffs(bn):

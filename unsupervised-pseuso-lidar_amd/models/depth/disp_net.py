@@ -101,6 +101,7 @@ class DispNetS(nn.Module):
             b = T.batchnorm(tape, seq[1], a, slab, train)
             h = T.conv(tape, spec_of(seq[2], 1, (k - 1) // 2, N.PAD_ZERO), b, act=N.ACT_RELU)
             o.append(h)
+        N.flush_bn_counters()
         hw = lambda t: (t.shape[1], t.shape[2])
 
         def up(name, x, ref):
