@@ -91,6 +91,14 @@ typedef struct mcav_wgrad_desc {
     int accumulate;
     float* dbias;           /* NULL or [Cout]: sum over pixels of dy (accumulated if accumulate != 0) */
     int tile;
+    /* The filter of conv(cat(up2(a), skip)) in two launches (all zero = one ordinary launch):
+     *  - the skip half: an ordinary launch with x1 = skip, Cin = its channels, Cin_total = the filter's input channels, ci_offset = where
+     *    the skip channels start in it (dw_oihw then addresses [Cout][Cin_total][kh][kw]);
+     *  - the upsampled half, upm = 1: x1 = a stored at [B, Hs/2, Ws/2, C1] (up1 = 1, C2 = 0, 3x3 stride 1 reflection pad, Hd = Hs, Wd = Ws even):
+     *    the merged-tap form of mcav_igemm_desc.w_upmerge -- per output parity class 4 taps on the low-resolution a, the reduction running over
+     *    low-resolution pixels (2.25x fewer MACs); the 16 partial filters are un-merged into the 9 taps when the slab is reduced.  dbias must be
+     *    NULL (the skip launch carries it).  Same result as one ordinary launch up to fp32 summation order. */
+    int upm, Cin_total, ci_offset;
 } mcav_wgrad_desc;
 
 size_t mcav_wgrad_workspace_bytes(const mcav_wgrad_desc* d);

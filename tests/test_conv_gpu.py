@@ -144,7 +144,12 @@ def test_decoder_level_fused_upsample_concat(dims):
         got = N.conv_fwd(spec, nhwc(a.detach()), nhwc(skip.detach()), up1=True, act=N.ACT_ELU, tile=tile)
         assert rel_err(nchw(got), want) < 2e-5, hex(tile)
     dyd = nhwc(dy)
-    N.conv_wgrad(spec, nhwc(a.detach()), dyd, x2=nhwc(skip.detach()), up1=True)
+    N.conv_wgrad(spec, nhwc(a.detach()), dyd, x2=nhwc(skip.detach()), up1=True, tile=0x1000)   # skip half + merged-tap upsampled half (bit 12)
+    assert rel_err(wp.grad, wt.grad) < 5e-5 and rel_err(bp.grad, bs.grad) < 5e-5
+    assert rel_err(wp.grad[:, :C1], wt.grad[:, :C1]) < 5e-5 and rel_err(wp.grad[:, C1:], wt.grad[:, C1:]) < 5e-5
+    wp.grad = None
+    bp.grad = None
+    N.conv_wgrad(spec, nhwc(a.detach()), dyd, x2=nhwc(skip.detach()), up1=True, tile=0x800)   # one ordinary launch (bit 11)
     assert rel_err(wp.grad, wt.grad) < 5e-5 and rel_err(bp.grad, bs.grad) < 5e-5
     da = N.conv_dgrad(spec, dyd, (2 * h, 2 * w_), n_begin=0, n_count=C1, pool=True)
     assert rel_err(nchw(da), a.grad) < 2e-5

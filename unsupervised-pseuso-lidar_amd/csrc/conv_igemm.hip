@@ -858,6 +858,8 @@ struct WgradParams {
     int slabN;                     // row stride of the slab (Cout rounded up to 16)
     int want_bias;
     int tab_cht_log2;              // wgrad_tab_kernel: log2 of the tiles per table chunk (>= 20: the whole split is one chunk)
+    int upm;                       // merged-tap upsample (mcav_wgrad_desc.upm): rows = 16 (class, merged tap) x Kp, pixels = LOW-resolution ones
+    int Hf, Wf;                    // upm: full-resolution size of dy (Hd, Wd hold the low-resolution one)
 };
 
 constexpr int KP = 32;   // pixels per K-tile of the wgrad GEMM
@@ -1116,7 +1118,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 //     split's last pixel, so the ragged last tile needs no masking.
 constexpr int WG_TABCAP = 4096;
 
-template <class T>
+// UPM: the weight gradient of the upsampled half of conv(cat(up2(a), skip)) in merged-tap form (see mcav_wgrad_desc.upm): the K
+// dimension runs over LOW-resolution pixels, a row tile belongs to one output parity class (py, px) and one or more of its 4 merged
+// taps; the A operand is the clamped low-resolution source of that tap, the B operand the class's dy pixel (2 y2 + py, 2 x2 + px) --
+// both through the offset table (dy is not linear in the low-resolution pixel index).  The 16 x Kp result rows are un-merged into
+// the 9 filter taps by the reduce kernel.
+template <class T, bool UPM>
 __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
     constexpr int BM = T::BM, BN = T::BN;
     __shared__ __attribute__((aligned(16))) float Xs[2][KP][BM];
@@ -1143,11 +1150,11 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
     const int tap_lo = m0 / p.Kp;
     const int tap_hi = min(p.taps - 1, (m0 + BM - 1) / p.Kp);
     const int NT = tap_hi - tap_lo + 1;
-    const bool two = g.C2 > 0;                            // second table: offsets into x2 (x1 may be the upsampled source)
+    const bool two = !UPM && g.C2 > 0;                    // second table: offsets into x2 (x1 may be the upsampled source)
     // chunking: CHT = 2^cht tiles per half-buffer; a split that fits is one chunk (cht large, second half never used)
     const int cht = p.tab_cht_log2;
     const int npc = min(T_total, 1 << min(cht, 20)) * KP;   // pixels per chunk
-    const int half = NT * (two ? 2 : 1) * npc;            // entries per half-buffer
+    const int half = (UPM ? NT + 1 : NT * (two ? 2 : 1)) * npc;      // entries per half-buffer (UPM: + the dy offsets)
 
     // chunk c -> half-buffer c & 1: [source][tap - tap_lo][pixel within the chunk]
     auto build_chunk = [&](int c) {
@@ -1158,6 +1165,16 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
             const int n = m / (p.Hd * p.Wd);
             const int r = m - n * (p.Hd * p.Wd);
             const int dy = r / p.Wd, dx = r - dy * p.Wd;
+            if constexpr (UPM) {           // (dy, dx) = low-resolution pixel (y2, x2); this row tile's class from its first merged tap
+                const int cls = tap_lo >> 2, py = cls >> 1, px = cls & 1;
+                for (int tl = 0; tl < NT; ++tl) {
+                    const int mtap = (tap_lo + tl) & 3;
+                    const int sy = min(max(dy - 1 + py + (mtap >> 1), 0), p.Hd - 1), sx = min(max(dx - 1 + px + (mtap & 1), 0), p.Wd - 1);
+                    tb[tl * npc + pl] = live ? (unsigned)(((n * p.Hd + sy) * p.Wd + sx) * g.C1) * 4u : OOB;
+                }
+                tb[NT * npc + pl] = live ? (unsigned)(((n * p.Hf + 2 * dy + py) * p.Wf + 2 * dx + px) * p.Cdy) * 4u : OOB;
+                continue;
+            }
             for (int tl = 0; tl < NT; ++tl) {
                 const int tap = tap_lo + tl;
                 const int ky = tap / p.kw, kx = tap - ky * p.kw;
@@ -1188,10 +1205,12 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
         a_ok = tap < p.taps;
     }
     const bool use2 = __builtin_amdgcn_readfirstlane((int)(two && ac >= g.C1)) != 0;
-    const unsigned bytes1 = (unsigned)((size_t)g.B * (g.up1 ? (g.Hs >> 1) * (g.Ws >> 1) : g.Hs * g.Ws) * g.C1 * 4);
+    const unsigned bytes1 = UPM ? (unsigned)((size_t)g.B * p.Hd * p.Wd * g.C1 * 4)
+                                : (unsigned)((size_t)g.B * (g.up1 ? (g.Hs >> 1) * (g.Ws >> 1) : g.Hs * g.Ws) * g.C1 * 4);
     const unsigned bytes2 = (unsigned)((size_t)g.B * g.Hs * g.Ws * g.C2 * 4);
     const __amdgpu_buffer_rsrc_t rsx = use2 ? make_rsrc(g.x2, bytes2) : make_rsrc(g.x1, bytes1);
-    const __amdgpu_buffer_rsrc_t rsy = make_rsrc(p.dy, (unsigned)((size_t)pix_end * p.Cdy * 4));      // ends at this split's last pixel
+    const __amdgpu_buffer_rsrc_t rsy = UPM ? make_rsrc(p.dy, (unsigned)((size_t)g.B * p.Hf * p.Wf * p.Cdy * 4))
+                                           : make_rsrc(p.dy, (unsigned)((size_t)pix_end * p.Cdy * 4));      // ends at this split's last pixel
     const int acc_ = use2 ? ac - g.C1 : ac;
     a_ok = a_ok && acc_ < (use2 ? g.C2 : g.C1);
     // Lanes on K-padding channels or on rows past Ktot add the out-of-range bit: they read zero (or, under an out-of-image tap whose
@@ -1203,26 +1222,38 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
     for (int j = 0; j < BPASS; ++j) {
         const int pl = bpix + j * BPIX, c = n0 + bcol * 4;
         const bool ok = pl < KP && c + 4 <= p.CoutLoad;
-        boff[j] = ok ? (unsigned)(((pix_begin + pl) * p.Cdy + p.dy_choff + c) * 4) : OOB;
+        boff[j] = ok ? (UPM ? (unsigned)((p.dy_choff + c) * 4) : (unsigned)(((pix_begin + pl) * p.Cdy + p.dy_choff + c) * 4)) : OOB;
     }
+    const int brow = NT * npc + (bpix < KP ? bpix : 0);      // UPM: this lane's position in the dy-offset row of a half-buffer
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const bool do_bias = p.want_bias && mt == 0;
     __syncthreads();
 
     unsigned toff[APASS];                                 // table values of the next tile to issue
+    unsigned tboff[UPM ? BPASS : 1];                      // UPM: dy pixel offsets of the next tile
     int u = 0;                                            // the issue pointer
     auto fetch = [&]() {
         const int uc = u >> cht, ul = u - (uc << cht);    // chunk of tile u and its position inside it
         const unsigned* tr = s_tab + (uc & 1) * half + trow + ul * KP;
 #pragma unroll
         for (int j = 0; j < APASS; ++j) toff[j] = tr[j * APIX];
+        if constexpr (UPM) {
+            const unsigned* tq = s_tab + (uc & 1) * half + brow + ul * KP;
+#pragma unroll
+            for (int j = 0; j < BPASS; ++j) tboff[j] = tq[j * BPIX < KP ? j * BPIX : 0];
+        }
     };
     auto issue = [&](f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
 #pragma unroll
         for (int j = 0; j < APASS; ++j) ra[j] = buf_load4(rsx, toff[j] + chan);
-        const int sb = u * KP * p.Cdy * 4;
+        if constexpr (UPM) {
 #pragma unroll
-        for (int j = 0; j < BPASS; ++j) rb[j] = buf_load4s(rsy, boff[j], sb);
+            for (int j = 0; j < BPASS; ++j) rb[j] = buf_load4(rsy, ((tboff[j] | boff[j]) & OOB) ? OOB : tboff[j] + boff[j]);
+        } else {
+            const int sb = u * KP * p.Cdy * 4;
+#pragma unroll
+            for (int j = 0; j < BPASS; ++j) rb[j] = buf_load4s(rsy, boff[j], sb);
+        }
         ++u;
         if (u < T_total) fetch();
     };
@@ -1372,8 +1403,10 @@ __global__ __launch_bounds__(256) void wgrad_presum_kernel(const float* slab, in
 // slab [splits][Ktot + 1][slabN] -> OIHW gradient (+ bias gradient), fixed summation order, optional accumulate.
 // One block owns 32 output channels x CI_T input channels x all taps: slab reads are coalesced along the output channel,
 // the tile is transposed through LDS, and each output channel's run of CI_T * taps floats is written contiguously.
+// upm: the slab holds 16 x Kp rows (class, merged tap, ci); filter tap (ky, kx) = the sum over the four classes of the merged tap it belongs to.
+// Cin_total / ci_off: the OIHW tensor written has Cin_total input channels and this launch owns [ci_off, ci_off + Cin) of them.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, int splits, int Ktot, int slabN, int Kp, int taps, int Cout, int Cin,
-                                                           int CI_T, float* dw, float* dbias, int accumulate) {
+                                                           int CI_T, float* dw, float* dbias, int accumulate, int upm, int Cin_total, int ci_off) {
     extern __shared__ float lds[];
     const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * CI_T;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -1384,9 +1417,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, in
         const int tap = idx / CI_T, r = idx - tap * CI_T, ci = ci0 + r;
         float sum = 0.f;
         if (ci < Cin && col_ok) {
-            const float* src = slab + (size_t)(tap * Kp + ci) * slabN + co0 + tx;
+            if (upm) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                for (int cls = 0; cls < 4; ++cls) {
+                    const int py = cls >> 1, px = cls & 1;
+                    const int ta = py == 0 ? (ky == 0 ? 0 : 1) : (ky == 2 ? 1 : 0), tb = px == 0 ? (kx == 0 ? 0 : 1) : (kx == 2 ? 1 : 0);
+                    const float* src = slab + (size_t)((cls * 4 + ta * 2 + tb) * Kp + ci) * slabN + co0 + tx;
+                    for (int k = 0; k < splits; ++k) sum += src[(size_t)k * split_stride];
+                }
+            } else {
+                const float* src = slab + (size_t)(tap * Kp + ci) * slabN + co0 + tx;
 #pragma unroll 8
-            for (int k = 0; k < splits; ++k) sum += src[(size_t)k * split_stride];
+                for (int k = 0; k < splits; ++k) sum += src[(size_t)k * split_stride];
+            }
         }
         lds[tx * stride + r * taps + tap] = sum;
     }
@@ -1401,7 +1444,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, in
     for (int e = threadIdx.x; e < 32 * run; e += 256) {
         const int col = e / run, q = e - col * run;
         if (co0 + col < Cout && q < valid_run) {
-            const size_t o = ((size_t)(co0 + col) * Cin + ci0) * taps + q;
+            const size_t o = ((size_t)(co0 + col) * Cin_total + ci_off + ci0) * taps + q;
             const float v = lds[col * stride + q];
             dw[o] = accumulate ? dw[o] + v : v;
         }
@@ -1675,12 +1718,24 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     if ((long)d->B * d->Hs * d->Ws * (d->C1 > d->C2 ? d->C1 : d->C2) * 4 >= 0x7fffffffL || M * d->Cdy * 4 >= 0x7fffffffL) return false;
     p.Mpix = (int)M;
     p.slabN = round_up(d->Cout, 16);
+    p.upm = 0; p.Hf = d->Hd; p.Wf = d->Wd;
+    if (d->upm) {      // merged-tap upsample half: 16 (class, merged tap) x Kp rows, reduction over the low-resolution pixels
+        if (d->mode != MCAV_G_DIRECT || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->sign != 1 || d->offset != -1 || d->pad_mode != MCAV_PAD_REFLECT ||
+            !d->up1 || d->C2 != 0 || d->Hd != d->Hs || d->Wd != d->Ws || (d->Hd & 1) || (d->Wd & 1) || d->dbias || d->Kp != d->C1 || (d->C1 & 15) ||
+            (d->Cdy & 3) || (d->dy_choff & 3) || (p.CoutLoad & 3))
+            return false;
+        p.upm = 1;
+        p.taps = 16; p.Ktot = 16 * d->Kp;
+        p.Hd = d->Hd / 2; p.Wd = d->Wd / 2;
+        p.Mpix = d->B * p.Hd * p.Wd;
+    }
     int tile = d->tile & 0xff;
     if (!tile) {
         if (d->Cout <= 16) tile = round_up(p.Ktot, 64) < round_up(p.Ktot, 256) ? 6 : 4;
         else if (d->Cout <= 32) tile = (d->C2 > 0 && d->C1 % 64 != 0) ? 7 : 3;
         else tile = 2;            // 64x64 beats 128x64 on every layer shape of the step (tools/conv_bench.py wgrad)
     }
+    if (p.upm) tile = d->Cout <= 16 ? 6 : 2;                     // 64-row tiles: a row tile never straddles a parity class (4 Kp rows each)
     if (tile != 1 && tile != 2 && tile != 3 && tile != 4 && tile != 6 && tile != 7) return false;
     pl.tile = tile;
     int BM, BN;
@@ -1707,7 +1762,7 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
             const int lo = mt * BM / d->Kp, hi = (mt * BM + BM - 1) / d->Kp < p.taps - 1 ? (mt * BM + BM - 1) / d->Kp : p.taps - 1;
             if (hi - lo + 1 > ntmax) ntmax = hi - lo + 1;
         }
-        const int epp = ntmax * (d->C2 > 0 ? 2 : 1);                      // table entries per pixel
+        const int epp = p.upm ? ntmax + 1 : ntmax * (d->C2 > 0 ? 2 : 1);  // table entries per pixel (upm: + the dy offset)
         if ((long)p.pix_per_split * epp <= WG_TABCAP) {
             pl.use_tab = true;                                            // one chunk
         } else if (epp <= 16) {
@@ -1718,7 +1773,8 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
         }
     }
     p.splits = (p.Mpix + p.pix_per_split - 1) / p.pix_per_split;
-    const int halo_splits = mcav_halo_wgrad_splits(d);           // narrow high-resolution layers: conv_halo.hip writes the slab partials
+    if (p.upm && !pl.use_tab) return false;                      // the merged form exists in the table-driven kernel only
+    const int halo_splits = p.upm ? 0 : mcav_halo_wgrad_splits(d);      // narrow high-resolution layers: conv_halo.hip writes the slab partials
     pl.use_halo = halo_splits > 0;
     if (pl.use_halo) { p.splits = halo_splits; pl.use_tab = false; }
     p.want_bias = d->dbias != nullptr;
@@ -1727,9 +1783,10 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     pl.per_group = pl.groups ? (p.splits + pl.groups - 1) / pl.groups : 0;
     if (pl.groups) pl.groups = (p.splits + pl.per_group - 1) / pl.per_group;
     pl.pre_bytes = align_up(sizeof(float) * (size_t)pl.groups * (p.Ktot + 1) * p.slabN, 256);
+    const int out_taps = p.upm ? 9 : p.taps;                     // filter taps written to OIHW
     int ci_t = 32;                                               // 32 x (CI_T * taps + 1) floats of LDS <= 64 KB ...
-    while (ci_t > 1 && ci_t * p.taps > 480) ci_t >>= 1;
-    if (ci_t * p.taps > 480) return false;
+    while (ci_t > 1 && ci_t * out_taps > 480) ci_t >>= 1;
+    if (ci_t * out_taps > 480) return false;
     const int co_tiles = (d->Cout + 31) / 32;                    // ... and enough blocks to fill the chip
     while (ci_t > 1 && co_tiles * ((d->Cin + ci_t - 1) / ci_t) < 256) ci_t >>= 1;
     pl.ci_t = ci_t;
@@ -1739,7 +1796,8 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
 template <class T>
 inline void launch_wgrad(const WgradParams& p, bool use_tab, hipStream_t s) {
     const int grid = p.splits * p.mtiles * p.ntiles;
-    if (use_tab) { wgrad_tab_kernel<T><<<grid, 256, 0, s>>>(p); return; }
+    if (use_tab && p.upm) { wgrad_tab_kernel<T, true><<<grid, 256, 0, s>>>(p); return; }
+    if (use_tab) { wgrad_tab_kernel<T, false><<<grid, 256, 0, s>>>(p); return; }
     const int wave_ch = T::BM / 4;          // channels one wavefront's A columns span
     const bool fast = (p.g.mode == MCAV_G_DIRECT || p.g.mode == MCAV_G_SMALLC) && (p.g.C1 & 3) == 0 && (p.g.C2 & 3) == 0 && (p.g.C2 == 0 || p.g.C1 % wave_ch == 0) &&
                       (p.CoutLoad & 3) == 0 && (p.Cdy & 3) == 0 && (p.dy_choff & 3) == 0 && p.Wd >= 16;
@@ -1772,7 +1830,8 @@ MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t wor
         default: return MCAV_E_INVALID;
     }
     const dim3 rgrid((d->Cout + 31) / 32, (d->Cin + pl.ci_t - 1) / pl.ci_t);
-    const size_t lds_bytes = sizeof(float) * 32 * (size_t)(pl.ci_t * pl.p.taps + 1);
+    const int out_taps = pl.p.upm ? 9 : pl.p.taps;
+    const size_t lds_bytes = sizeof(float) * 32 * (size_t)(pl.ci_t * out_taps + 1);
     const float* rsrc = pl.p.slab;
     int rsplits = pl.p.splits;
     if (pl.groups) {
@@ -1782,8 +1841,10 @@ MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t wor
         rsrc = pre;
         rsplits = pl.groups;
     }
-    wgrad_reduce_kernel<<<rgrid, 256, lds_bytes, s>>>(rsrc, rsplits, pl.p.Ktot, pl.p.slabN, pl.p.Kp, pl.p.taps, d->Cout, d->Cin, pl.ci_t,
-                                                     d->dw_oihw, d->dbias, d->accumulate);
+    const int cin_total = d->Cin_total > 0 ? d->Cin_total : d->Cin;
+    if (d->ci_offset < 0 || d->ci_offset + d->Cin > cin_total) return MCAV_E_INVALID;
+    wgrad_reduce_kernel<<<rgrid, 256, lds_bytes, s>>>(rsrc, rsplits, pl.p.Ktot, pl.p.slabN, pl.p.Kp, out_taps, d->Cout, d->Cin, pl.ci_t,
+                                                     d->dw_oihw, d->dbias, d->accumulate, pl.p.upm, cin_total, d->ci_offset);
     return launch_status();
 }
 

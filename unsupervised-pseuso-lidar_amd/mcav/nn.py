@@ -31,7 +31,7 @@ class WgradDesc(ctypes.Structure):
                 ("kh", c_i), ("kw", c_i), ("Kp", c_i),
                 ("mode", c_i), ("stride", c_i), ("sign", c_i), ("offset", c_i), ("pad_mode", c_i),
                 ("dy", c_p), ("Hd", c_i), ("Wd", c_i), ("Cdy", c_i), ("dy_choff", c_i), ("Cout", c_i), ("Cin", c_i),
-                ("dw_oihw", c_p), ("accumulate", c_i), ("dbias", c_p), ("tile", c_i)]
+                ("dw_oihw", c_p), ("accumulate", c_i), ("dbias", c_p), ("tile", c_i), ("upm", c_i), ("Cin_total", c_i), ("ci_offset", c_i)]
 
 
 L.register({
@@ -373,6 +373,19 @@ def conv_wgrad(spec, x1, dy, x2=None, up1=False, tile=0):
     d.tile = tile
     flops = 2.0 * B * dy.shape[1] * dy.shape[2] * spec.cout * spec.cin * spec.kh * spec.kw
     tag = "pix=%d Cout=%d Ktot=%dx%d s%d" % (B * dy.shape[1] * dy.shape[2], spec.cout, spec.cin, spec.kh * spec.kw, spec.stride)
+    c1 = x1.shape[3]
+    if (up1 and x2 is not None and spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad == 1 and spec.pad_mode == PAD_REFLECT
+            and c1 % 16 == 0 and x2.shape[3] % 16 == 0 and Hs % 2 == 0 and Ws % 2 == 0 and not (tile >> 11) & 1
+            and (spec.cout >= 64 or (tile >> 12) & 1)):       # measured: 32 output channels are faster in one launch (bit 12 forces)
+        # two launches: the skip tensor's channels as an ordinary weight gradient, the upsampled map's in merged-tap form (mcav_conv.h)
+        c2 = x2.shape[3]
+        d.x1, d.x2, d.C1, d.C2, d.up1, d.Kp = P(x2), None, c2, 0, 0, up16(c2)
+        d.Cin, d.Cin_total, d.ci_offset, d.upm = c2, spec.cin, c1, 0
+        launch_wgrad(d, (x2, dy), flops * c2 / spec.cin, tag + " [skip half]")
+        d.x1, d.C1, d.up1, d.Kp = P(x1), c1, 1, c1
+        d.Cin, d.ci_offset, d.upm, d.dbias, d.tile = c1, 0, 1, None, 0
+        launch_wgrad(d, (x1, dy), flops * c1 / spec.cin, tag + " [upsampled half, merged taps]")
+        return
     launch_wgrad(d, (x1, x2, dy), flops, tag)
 
 
