@@ -54,7 +54,7 @@ def synthetic_samples(B, H, W, rank, step=0):
     return synthetic_batch(B, H, W, seed=1234 + 1000 * rank + step)
 
 
-def build(device, lr=1e-4, seed=0, depth_layers=18):
+def build(device, lr=1e-4, seed=0, depth_layers=18, ssim=False):
     from models.depth.resnet_dispnet import DispResNet
     from models.pose.pose_net import PoseNet
     from mcav.optim import FusedAdam
@@ -66,7 +66,7 @@ def build(device, lr=1e-4, seed=0, depth_layers=18):
     depth.to(device).train()
     pose.to(device).train()
     opt = FusedAdam(list(depth.parameters()) + list(pose.parameters()), lr)
-    return depth, pose, opt, Losses()
+    return depth, pose, opt, Losses(ssim=ssim)
 
 
 def make_step(depth, pose, opt, crit, samples, pair=True, graph=False):
@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--depth-layers", type=int, default=18, help="ResNet depth of the encoder (18 = the metric's config; 50 = BASELINE.json configs[3])")
+    ap.add_argument("--ssim", action="store_true", help="photometric term = 0.85 SSIM + 0.15 L1 (Losses(ssim=True); BASELINE.json configs[3] "
+                                                        "stresses this kernel) instead of the reference's live L1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--separate-passes", action="store_true", help="run the two depth passes as separate launch sets (default: stacked)")
@@ -164,7 +166,7 @@ def main():
     torch.cuda.set_device(device)
     B, H, W = args.batch, args.height, args.width
 
-    depth, pose, opt, crit = build(device, depth_layers=args.depth_layers)
+    depth, pose, opt, crit = build(device, depth_layers=args.depth_layers, ssim=args.ssim)
     mdist.broadcast_parameters(opt.arena())
     if os.environ.get("MCAV_DP_OVERLAP", "1") != "0":
         mdist.enable_overlap(opt.arena())          # N > 1: bucketed all-reduce behind the rest of backward (no-op on one rank)
@@ -197,9 +199,10 @@ def main():
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "%s: per-GPU batch=%d, %dx%d KITTI-shaped triplets, ResNet-%d depth encoder + 6-DoF PoseNet, "
-                                  "fp32, one step = 2x depth fwd + pose fwd + warp/L1/smooth loss + backward + Adam%s" %
-                                  ("BASELINE.json configs[1]" if (B, H, W, args.depth_layers) == (12, 192, 640, 18) else "variant of BASELINE.json configs[1]",
-                                   B, H, W, args.depth_layers, " + 1 RCCL all-reduce of the gradient arena" if world > 1 else ""),
+                                  "fp32, one step = 2x depth fwd + pose fwd + warp/%s/smooth loss + backward + Adam%s" %
+                                  ("BASELINE.json configs[1]" if (B, H, W, args.depth_layers, args.ssim) == (12, 192, 640, 18, False)
+                                   else "variant of BASELINE.json configs[1]",
+                                   B, H, W, args.depth_layers, "SSIM+L1" if args.ssim else "L1", " + 1 RCCL all-reduce of the gradient arena" if world > 1 else ""),
                       "global_batch": B * world, "parallelism": "dp%d" % world},
            "loss": [round(float(l.detach()), 6) for l in loss], "hipgraph": bool(getattr(make_step, "graphed", False))}
 
@@ -233,6 +236,8 @@ def main():
             a[2] += 1
         ach = flops / (ms * 1e-3) / 1e12
         conv_traffic, warp_traffic = measured_traffic() if (B, H, W) == (12, 192, 640) else (None, None)
+        if args.ssim:
+            warp_traffic = None
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": conv_traffic,
                            "traffic_note": "HBM bytes of the conv stage per step, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the rocprofv3 --pmc passes "
@@ -247,7 +252,8 @@ def main():
             lbytes = 52.0 * B * H * W
             out["roofline_warp"] = {"bound": "hbm", "achieved": round(lbytes / (lms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": round(lbytes / (lms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": warp_traffic,
-                                    "kernel": "warp_loss_kernel (+prepare/finalize), 52 B/pixel x %d pixels" % (B * H * W), "ms": round(lms, 4)}
+                                    "kernel": "%s (+prepare/finalize), 52 B/pixel x %d pixels" % ("warp_loss_ssim_kernel" if args.ssim else "warp_loss_kernel", B * H * W),
+                                    "ms": round(lms, 4)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B, H, W)
     if rank == 0:

@@ -45,6 +45,7 @@ int mcav_abi_version(void);
 #define MCAV_WL_SKIP_IF_UNIT 2u   /* return without touching outputs when upstream[0]==upstream[1]==1 */
 #define MCAV_WL_NO_SMOOTH 4u      /* leave the smoothness term out (used for scales > 0 of multi-scale nets) */
 #define MCAV_WL_INPUT_DEPTH 8u    /* disp_t / disp_r0 already hold depths; gradients are w.r.t. depth */
+#define MCAV_WL_SSIM 16u          /* photometric term = 0.85 * SSIM distance + 0.15 * L1 (reference losses.py:12-54, weights of :77) instead of L1 */
 
 size_t mcav_warp_loss_workspace_bytes(int B, int H, int W);
 

@@ -180,6 +180,35 @@ def case_ssim():
          ka3=np.array([float(s3.mean()), float(s3.min()), float(s3.max())]))
 
 
+# ------------------------------------------------------------------ 4b. SSIM + L1 photometric mix over the live path's three warps
+def case_loss_ssim():
+    """The reference cannot run its SSIM photometric loss end to end (self.SSIM is commented out, losses.py:59), so this case composes
+    the reference's OWN pieces the way its live path composes the L1 terms: ref inverse_warp (pose_geometry.py:201-229), ref
+    SSIM.standard_loss (losses.py:12-54), the 0.85 / 0.15 weights of losses.py:77, the three warps and means of losses.py:183-240."""
+    g = torch.Generator().manual_seed(21)
+    B, H, W = 4, 40, 72                        # ragged against the kernel's 32 x 32 tiles
+    K = kmat(B, H, W)
+    tgt, r0, r1 = (smooth_images(g, B, H, W) for _ in range(3))
+    disp_t = torch.rand(B, 1, H, W, generator=g).requires_grad_()
+    disp_r = torch.rand(B, 1, H, W, generator=g).requires_grad_()
+    poses = (0.02 * torch.randn(B, 2, 6, generator=g)).requires_grad_()
+    depths = ref_pg.disp_to_depth([[disp_t], [disp_r]])
+    ssim = ref_losses.SSIM()
+
+    def photo(pred, target):
+        return (0.85 * ssim.standard_loss(pred, target) + 0.15 * torch.abs(target - pred)).mean()
+
+    Dt, Dr = depths[0][0][:, 0], depths[1][0][:, 0]
+    w0 = ref_pg.inverse_warp(r0, Dt, poses[:, 0], K, False)
+    w1 = ref_pg.inverse_warp(r1, Dt, poses[:, 1], K, False)
+    w2 = ref_pg.inverse_warp(tgt, Dr, poses[:, 0], K, True)
+    loss_mam = (torch.stack([photo(w0, tgt), photo(w1, tgt)]).mean() + torch.stack([photo(w2, r1)]).mean()) / 2
+    loss_smooth = ref_losses.Losses().smooth_loss(depths[0])
+    (loss_mam + loss_smooth).backward()
+    save("loss_ssim.npz", tgt=npy(tgt), ref0=npy(r0), ref1=npy(r1), disp_t=npy(disp_t), disp_r=npy(disp_r), poses=npy(poses), K=npy(K),
+         loss=np.array([float(loss_mam), float(loss_smooth)]), g_disp_t=npy(disp_t.grad), g_disp_r=npy(disp_r.grad), g_poses=npy(poses.grad))
+
+
 # ------------------------------------------------------------------ 5. smoothness + disp_to_depth
 def case_smooth():
     g = torch.Generator().manual_seed(8)
@@ -357,6 +386,7 @@ if __name__ == "__main__":
     case_loss_ka1()
     case_warp_edge()
     case_ssim()
+    case_loss_ssim()
     case_smooth()
     keys = {"PoseNet": case_posenet(), "DepthDecoder": case_decoder(), "DispResNet": case_dispresnet(),
             "DispNetS": case_dispnets(), "PoseFc": case_posefc()}

@@ -71,6 +71,56 @@ def test_losses_ka1(golden):
     assert rel_err(p.grad, g["g_poses"]) < 2e-2
 
 
+@pytest.mark.parametrize("up", [None, (1.0, 0.0), (0.7, 1.3)])
+def test_losses_ssim_vs_reference_golden(golden, up):
+    """Losses(ssim=True): the fused SSIM + L1 kernel against the composition of the reference's own pieces (loss_ssim.npz)."""
+    from losses import Losses
+    g = golden("loss_ssim.npz")
+    disp_t, disp_r, poses = T(g["disp_t"]).requires_grad_(), T(g["disp_r"]).requires_grad_(), T(g["poses"]).requires_grad_()
+    out = Losses(ssim=True).forward(T(g["tgt"]), [T(g["ref0"]), T(g["ref1"])], [[disp_t], [disp_r]], poses, T(g["K"]), None)
+    assert abs(float(out[0]) - g["loss"][0]) < 3e-6 * abs(g["loss"][0])
+    assert abs(float(out[1]) - g["loss"][1]) < 3e-6 * abs(g["loss"][1])
+    if up is None:
+        sum(out).backward()
+        grad_close(disp_t.grad, g["g_disp_t"])
+        grad_close(disp_r.grad, g["g_disp_r"])
+        assert float((poses.grad.cpu() - torch.from_numpy(g["g_poses"])).abs().max()) <= 1e-3 * np.abs(g["g_poses"]).max()
+    else:
+        from oracle import losses as ol
+        (up[0] * out[0] + up[1] * out[1]).backward()
+        dt, dr, p = (torch.from_numpy(g[k]).requires_grad_() for k in ("disp_t", "disp_r", "poses"))
+        o = ol.losses_forward(torch.from_numpy(g["tgt"]), [torch.from_numpy(g["ref0"]), torch.from_numpy(g["ref1"])], [[dt], [dr]], p,
+                              torch.from_numpy(g["K"]), ssim_weight=0.85)
+        (up[0] * o[0] + up[1] * o[1]).backward()
+        grad_close(disp_t.grad, dt.grad)
+        grad_close(disp_r.grad, dr.grad)
+        assert float((poses.grad.cpu() - p.grad).abs().max()) <= 1e-3 * float(p.grad.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 3, 3), (2, 5, 7), (2, 33, 65), (3, 64, 96), (1, 31, 34)])
+def test_losses_ssim_vs_oracle_shapes(B, H, W):
+    """Edge geometry of the fused SSIM kernel: images smaller than the halo (every pixel folds reflections from both sides), tiles that
+    end one pixel into / before the image border, several tiles per image."""
+    from losses import Losses
+    from oracle import losses as ol
+    gen = torch.Generator().manual_seed(100 + H)
+    K = torch.tensor([[0.58 * W, 0, 0.5 * W], [0, 1.92 * H, 0.5 * H], [0, 0, 1]], dtype=torch.float64).repeat(B, 1, 1)
+    imgs = [torch.nn.functional.avg_pool2d(torch.nn.functional.pad(torch.randn(B, 3, H, W, generator=gen), (1, 1, 1, 1), mode="reflect"), 3, 1)
+            for _ in range(3)]
+    disp_t, disp_r = torch.rand(B, 1, H, W, generator=gen), torch.rand(B, 1, H, W, generator=gen)
+    poses = 0.02 * torch.randn(B, 2, 6, generator=gen)
+    a = [t.clone().requires_grad_() for t in (disp_t, disp_r, poses)]
+    o = ol.losses_forward(imgs[0], imgs[1:], [[a[0]], [a[1]]], a[2], K, ssim_weight=0.85)
+    sum(o).backward()
+    d = [t.to(DEV).requires_grad_() for t in (disp_t, disp_r, poses)]
+    out = Losses(ssim=True).forward(imgs[0].to(DEV), [i.to(DEV) for i in imgs[1:]], [[d[0]], [d[1]]], d[2], K.to(DEV), None)
+    assert abs(float(out[0]) - float(o[0])) < 5e-6 * abs(float(o[0])) and abs(float(out[1]) - float(o[1])) < 5e-6 * abs(float(o[1]))
+    sum(out).backward()
+    grad_close(d[0].grad, a[0].grad, frac=5e-3, l2=2e-3)
+    grad_close(d[1].grad, a[1].grad, frac=5e-3, l2=2e-3)
+    assert float((d[2].grad.cpu() - a[2].grad).abs().max()) <= 2e-3 * float(a[2].grad.abs().max())
+
+
 def test_inverse_warp_vs_reference_golden(golden):
     from geometry.pose_geometry import inverse_warp
     g = golden("loss_small.npz")

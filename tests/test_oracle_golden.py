@@ -84,6 +84,17 @@ def test_loss_ka1(golden):
     assert rel_err(disp_t.grad[1, 0, 17], g["g_disp_t_row"]) < 1e-4
 
 
+def test_loss_ssim(golden):
+    """SSIM + L1 photometric mix: the oracle against the composition of the reference's own inverse_warp / SSIM / smooth_loss."""
+    g = golden("loss_ssim.npz")
+    disp_t, disp_r, poses = T(g["disp_t"]).requires_grad_(), T(g["disp_r"]).requires_grad_(), T(g["poses"]).requires_grad_()
+    out = ol.losses_forward(T(g["tgt"]), [T(g["ref0"]), T(g["ref1"])], [[disp_t], [disp_r]], poses, T(g["K"]), ssim_weight=0.85)
+    assert np.allclose([float(out[0]), float(out[1])], g["loss"], rtol=1e-6)
+    sum(out).backward()
+    assert rel_err(disp_t.grad, g["g_disp_t"]) < 1e-5 and rel_err(disp_r.grad, g["g_disp_r"]) < 1e-5
+    assert rel_err(poses.grad, g["g_poses"]) < 1e-5
+
+
 def test_warp_edge(golden):
     g = golden("warp_edge.npz")
     img, K = T(g["img"]), T(g["K"])

@@ -83,6 +83,8 @@ __global__ void pose_prepare_kernel(const float* poses, const void* K, const flo
     out[b] = pc;
 }
 
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
 // Reduce N per-thread floats over a 256-thread block and store them at dst[0..N).
 template <int N>
 __device__ __forceinline__ void block_reduce_store(float* acc, float* dst, float (*sred)[SLAB]) {
@@ -160,6 +162,230 @@ __global__ __launch_bounds__(256) void warp_loss_kernel(WLArgs a) {
         }
         a.d_disp_t[(size_t)b * plane + pix] = in_depth ? dDt : dDt * (-10.0f * Dt * Dt);
         a.d_disp_r0[(size_t)b * plane + pix] = in_depth ? dDr : dDr * (-10.0f * Dr * Dr);
+    }
+    const int nblk = gridDim.x * gridDim.y;
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    block_reduce_store<NACC>(acc, a.slab + ((size_t)b * nblk + blk) * SLAB, sred);
+}
+
+// ---------------------------------------------------------------------------------------------- SSIM + L1 photometric (MCAV_WL_SSIM)
+// The north_star's photometric mix, 0.85 * SSIM distance + 0.15 * L1 (weights of losses.py:77, SSIM of losses.py:12-54), fused with
+// the warp, forward and backward in one pass.  Per 32 x 32 tile and per warp the three warped channel planes and the three target
+// planes of the tile + 2 halo are staged in LDS (values at padded positions -1 / H / W are the warp at the REFLECTED pixel, which is
+// what ReflectionPad2d of the warped image holds); per channel the 3x3 window statistics are evaluated on tile + 1 halo and turned
+// into three coefficient fields -- dS(p)/dx(q) = a(p) + b(p) x(q) + c(p) y(q) for every q in p's window -- so that the gradient at a
+// pixel is a second 3x3 gather of (a, b, c) (plus the windows it enters through the reflection), no atomics.
+constexpr int SS_P = WLH + 2;      // statistics region: tile + 1 halo
+
+struct SsimPoint { float S, a, b, c; };
+
+// x: 3x3 window of the warped image, y: of the target, row-major.  S = clamp((1 - SSIM) / 2, 0, 1); (a, b, c): see above.
+__device__ __forceinline__ SsimPoint ssim_point(const float* x, const float* y) {
+    // no fma contraction: SSIM(x, x) must cancel exactly, as in ssim_kernel and in the reference
+#pragma clang fp contract(off)
+    float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { sx += x[i]; sy += y[i]; sxx += x[i] * x[i]; syy += y[i] * y[i]; sxy += x[i] * y[i]; }
+    const float C1 = 1e-4f, C2 = 9e-4f, k = 1.0f / 9.0f;
+    const float mx = sx * k, my = sy * k;
+    const float mxy = mx * my, mxx = mx * mx, myy = my * my;
+    const float vx = sxx * k - mxx, vy = syy * k - myy, vxy = sxy * k - mxy;
+    const float A1 = 2.f * mxy + C1, A2 = 2.f * vxy + C2, B1 = mxx + myy + C1, B2 = vx + vy + C2;
+    const float den = B1 * B2;
+    const float ssim = (A1 * A2) / den;
+    const float v = (1.0f - ssim) / 2.0f;
+    SsimPoint o;
+    o.S = fminf(fmaxf(v, 0.0f), 1.0f);
+    const float m = (v >= 0.0f && v <= 1.0f) ? -0.5f * (2.0f / 9.0f) / den : 0.0f;       // d clamp((1 - ssim) / 2) / d ssim, times 2 / (9 den)
+    o.a = m * (my * (A2 - A1) - ssim * mx * (B2 - B1));
+    o.b = m * (-ssim * B1);
+    o.c = m * A1;
+    return o;
+}
+
+__global__ __launch_bounds__(256) void warp_loss_ssim_kernel(WLArgs a) {
+    const float g0 = a.upstream[0], g1 = a.upstream[1];
+    if ((a.flags & MCAV_WL_SKIP_IF_UNIT) && g0 == 1.0f && g1 == 1.0f) return;
+    __shared__ float sD[WL_LH][LW + 1];
+    __shared__ float sX[3][WL_LH][LW + 1];
+    __shared__ float sT[3][WL_LH][LW + 1];
+    __shared__ float sC[3][SS_P][SS_P + 1];
+    __shared__ float sred[4][SLAB];
+    const int H = a.H, W = a.W, b = blockIdx.z;
+    const int bx0 = blockIdx.x * TW, by0 = blockIdx.y * WLH;
+    const size_t plane = (size_t)H * W;
+    const bool in_depth = (a.flags & MCAV_WL_INPUT_DEPTH) != 0;
+    const float* dt = a.disp_t + (size_t)b * plane;
+    const float* dr = a.disp_r0 + (size_t)b * plane;
+    for (int i = threadIdx.x; i < WL_LH * LW; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = by0 - HALO + ly, gx = bx0 - HALO + lx;
+        float D = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const float v = dt[(size_t)gy * W + gx];
+            D = in_depth ? v : 1.0f / (10.0f * v + 0.01f);
+        }
+        sD[ly][lx] = D;
+    }
+    const PrepConst& pc = a.pc[b];
+    const float* img_t = a.tgt + (size_t)b * 3 * plane;
+    const float* img_r0 = a.ref0 + (size_t)b * 3 * plane;
+    const float* img_r1 = a.ref1 + (size_t)b * 3 * plane;
+    const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;
+    const int x = bx0 + tx;
+    const float invN = 1.0f / (float)((size_t)a.B * 3 * plane);
+    const float WS = 0.85f, WL1 = 0.15f;              // losses.py:77
+    constexpr int NONE = -(1 << 30);
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    float dDt[WL_SUB], dDr[WL_SUB], Dr[WL_SUB];
+#pragma unroll
+    for (int sub = 0; sub < WL_SUB; ++sub) {
+        dDt[sub] = 0.f; dDr[sub] = 0.f; Dr[sub] = 0.f;
+        const int y = by0 + sub * TH + ty0;
+        if (x < W && y < H) {
+            const float vr = dr[(size_t)y * W + x];
+            Dr[sub] = in_depth ? vr : 1.0f / (10.0f * vr + 0.01f);
+        }
+    }
+
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        const float* src = w == 0 ? img_r0 : (w == 1 ? img_r1 : img_t);
+        const float* tar = w == 2 ? img_r1 : img_t;
+        const float* P = pc.sc.w[w].P;
+        const float lw = a.tw[w] * invN, gw = g0 * lw;
+        __syncthreads();                       // sD is filled (w == 0) / the previous warp's readers are done
+        // ---- phase 1: warped and target planes on tile + 2 halo
+        for (int i = threadIdx.x; i < WL_LH * LW; i += 256) {
+            const int ly = i / LW, lx = i - ly * LW;
+            const int gy = by0 - HALO + ly, gx = bx0 - HALO + lx;
+            float xv[3] = {0.f, 0.f, 0.f}, tv[3] = {0.f, 0.f, 0.f};
+            if (gy >= -1 && gy <= H && gx >= -1 && gx <= W) {
+                const int ry = reflect1(gy, H), rx = reflect1(gx, W);
+                float D;
+                if (w < 2) D = sD[ry - by0 + HALO][rx - bx0 + HALO];
+                else {
+                    const float v = dr[(size_t)ry * W + rx];
+                    D = in_depth ? v : 1.0f / (10.0f * v + 0.01f);
+                }
+                const Ray r = pixel_ray(pc.sc.Kinv, (float)rx, (float)ry);
+                const Tap t = project_pixel(P, r, D, H, W);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) xv[c] = bilinear(src + c * plane, W, t).v;
+                if (w != 1) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) tv[c] = tar[c * plane + (size_t)ry * W + rx];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                sX[c][ly][lx] = xv[c];
+                if (w != 1) sT[c][ly][lx] = tv[c];         // warps 0 and 1 share the target
+            }
+        }
+        __syncthreads();
+        float gp0[WL_SUB], gp1[WL_SUB], gp2[WL_SUB];        // d loss / d warped value at the thread's own pixels, per channel
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) {
+            // ---- phase 2: window statistics -> S and the gradient coefficient fields on tile + 1 halo
+            for (int i = threadIdx.x; i < SS_P * SS_P; i += 256) {
+                const int py = i / SS_P, px = i - py * SS_P;
+                const int gy = by0 - 1 + py, gx = bx0 - 1 + px;
+                SsimPoint o;
+                o.S = 0.f; o.a = 0.f; o.b = 0.f; o.c = 0.f;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    float xw[9], yw[9];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) { xw[dy * 3 + dx] = sX[c][py + dy][px + dx]; yw[dy * 3 + dx] = sT[c][py + dy][px + dx]; }
+                    o = ssim_point(xw, yw);
+                    if (py >= 1 && py <= WLH && px >= 1 && px <= TW) acc[0] += lw * (WS * o.S + WL1 * fabsf(xw[4] - yw[4]));
+                }
+                sC[0][py][px] = o.a; sC[1][py][px] = o.b; sC[2][py][px] = o.c;
+            }
+            __syncthreads();
+            // ---- phase 3: gather the coefficient fields of every window the thread's own pixels take part in
+#pragma unroll
+            for (int sub = 0; sub < WL_SUB; ++sub) {
+                const int ty = sub * TH + ty0, y = by0 + ty;
+                if (c == 0) gp0[sub] = 0.f; else if (c == 1) gp1[sub] = 0.f; else gp2[sub] = 0.f;
+                if (!(x < W && y < H)) continue;
+                float SA = 0.f, SB = 0.f, SC = 0.f;
+                // the pixel's own 3x3 neighbourhood: always inside the statistics region, zero outside the image
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) { SA += sC[0][ty + dy][tx + dx]; SB += sC[1][ty + dy][tx + dx]; SC += sC[2][ty + dy][tx + dx]; }
+                if (y == 1 || y == H - 2 || x == 1 || x == W - 2) {
+                    // one pixel in from the border: the pixel is also the reflection at padded row -1 / H or column -1 / W
+                    for (int yi = 0; yi < 3; ++yi) {
+                        const int yc = yi == 0 ? y : (yi == 1 ? (y == 1 ? -1 : NONE) : (y == H - 2 ? H : NONE));
+                        if (yc == NONE) continue;
+                        for (int xi = (yi == 0 ? 1 : 0); xi < 3; ++xi) {
+                            const int xc = xi == 0 ? x : (xi == 1 ? (x == 1 ? -1 : NONE) : (x == W - 2 ? W : NONE));
+                            if (xc == NONE) continue;
+                            for (int dy = -1; dy <= 1; ++dy) {
+                                const int qy = yc + dy;
+                                if (qy < 0 || qy >= H) continue;
+                                for (int dx = -1; dx <= 1; ++dx) {
+                                    const int qx = xc + dx;
+                                    if (qx < 0 || qx >= W) continue;
+                                    SA += sC[0][qy - by0 + 1][qx - bx0 + 1];
+                                    SB += sC[1][qy - by0 + 1][qx - bx0 + 1];
+                                    SC += sC[2][qy - by0 + 1][qx - bx0 + 1];
+                                }
+                            }
+                        }
+                    }
+                }
+                const float xq = sX[c][ty + HALO][tx + HALO], tq = sT[c][ty + HALO][tx + HALO];
+                const float gv = gw * (WL1 * sgn(xq - tq) + WS * (SA + xq * SB + tq * SC));
+                if (c == 0) gp0[sub] = gv; else if (c == 1) gp1[sub] = gv; else gp2[sub] = gv;
+            }
+            __syncthreads();                   // sC is rewritten by the next channel
+        }
+        // ---- phase 4: chain through the bilinear sample to the sampling position, the depth and P
+#pragma unroll
+        for (int sub = 0; sub < WL_SUB; ++sub) {
+            const int ty = sub * TH + ty0, y = by0 + ty;
+            if (!(x < W && y < H)) continue;
+            const Ray r = pixel_ray(pc.sc.Kinv, (float)x, (float)y);
+            const Tap t = project_pixel(P, r, w < 2 ? sD[ty + HALO][tx + HALO] : Dr[sub], H, W);
+            float gix = 0.f, giy = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const Sample sm = bilinear(src + c * plane, W, t);
+                const float gv = c == 0 ? gp0[sub] : (c == 1 ? gp1[sub] : gp2[sub]);
+                gix += gv * sm.dvdx;
+                giy += gv * sm.dvdy;
+            }
+            const float d = backproject_grad(P, r, t, gix, giy, H, W, acc + 2 + 12 * w);
+            if (w < 2) dDt[sub] += d; else dDr[sub] += d;
+        }
+    }
+
+#pragma unroll
+    for (int sub = 0; sub < WL_SUB; ++sub) {
+        const int ty = sub * TH + ty0, y = by0 + ty;
+        if (!(x < W && y < H)) continue;
+        const int cy = ty + HALO, cx = tx + HALO;
+        const size_t pix = (size_t)y * W + x;
+        const float Dt = sD[cy][cx];
+        float d = dDt[sub];
+        if (!(a.flags & MCAV_WL_NO_SMOOTH)) {
+            const float cxx = 1.0f / (float)((size_t)a.B * H * (W - 2));
+            const float cyy = 1.0f / (float)((size_t)a.B * (H - 2) * W);
+            const float cxy = 2.0f / (float)((size_t)a.B * (H - 1) * (W - 1));
+            float gs = 0.f, ls = 0.f;
+            smooth_terms([&](int dy, int dx) { return sD[cy + dy][cx + dx]; }, x, y, H, W, cxx, cyy, cxy, ls, gs);
+            acc[1] += ls;
+            d += g1 * gs;
+        }
+        a.d_disp_t[(size_t)b * plane + pix] = in_depth ? d : d * (-10.0f * Dt * Dt);
+        a.d_disp_r0[(size_t)b * plane + pix] = in_depth ? dDr[sub] : dDr[sub] * (-10.0f * Dr[sub] * Dr[sub]);
     }
     const int nblk = gridDim.x * gridDim.y;
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
@@ -350,7 +576,6 @@ __global__ void disp_to_depth_bwd_kernel(const float* disp, const float* dD, flo
     }
 }
 
-__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 __global__ __launch_bounds__(256) void ssim_kernel(const float* xs, const float* ys, int N, int H, int W, float C1, float C2, float* out) {
     // no fma contraction in this kernel: SSIM(x, x) must cancel exactly (num == den), as it does in the reference
@@ -486,7 +711,8 @@ MCAV_EXPORT int mcav_warp_loss_fwd_bwd(const float* tgt, const float* ref0, cons
     a.tw[1] = term_weights ? term_weights[1] : 0.25f;
     a.tw[2] = term_weights ? term_weights[2] : 0.5f;
     const dim3 wl_grid((W + TW - 1) / TW, (H + WLH - 1) / WLH, B);
-    warp_loss_kernel<<<wl_grid, 256, 0, s>>>(a);
+    if (flags & MCAV_WL_SSIM) warp_loss_ssim_kernel<<<wl_grid, 256, 0, s>>>(a);
+    else warp_loss_kernel<<<wl_grid, 256, 0, s>>>(a);
     warp_loss_finalize_kernel<<<B, 1024, 0, s>>>(slab, (int)(wl_grid.x * wl_grid.y), pc, poses, up, flags, d_poses, sl, reinterpret_cast<unsigned*>(ones) + 2, B, losses);
     return launch_status();
 }

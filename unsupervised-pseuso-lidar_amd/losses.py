@@ -80,32 +80,47 @@ class SSIM:
 
 
 class Losses:
-    def __init__(self):
+    """`Losses()` is the reference's live loss (L1 photometric, losses.py:183-240).  `Losses(ssim=True)` -- or setting `.ssim` on an
+    instance, which is what `loss: {ssim: true}` in a trainer config does -- switches the photometric term of every warp to
+    0.85 * SSIM.standard_loss(warped, target) + 0.15 * |target - warped| (the mix of the reference's dormant
+    compute_photometric_loss, losses.py:66-77, without its mean + 0.5 std clip), evaluated by the same fused kernel (MCAV_WL_SSIM)."""
+
+    def __init__(self, ssim=False):
         self.clip_loss = 0.5
+        self.ssim = bool(ssim)
+
+    def _flags(self, n_scales):
+        if not self.ssim:
+            return 0
+        if n_scales != 1:
+            raise L.MCAVError("Losses(ssim=True): the SSIM photometric mix is implemented for single-scale disparity lists only")
+        return L.WL_SSIM
 
     def forward(self, tgt_img, ref_imgs, disparity, poses, intrinsics, gt=None):
         """-> [loss_mam, loss_smooth].  disparity = [disps(tgt), disps(ref0)], each a list over scales."""
         disp_t, disp_r = disparity[0], disparity[1]
         n = len(disp_t)
+        ssim_flag = self._flags(max(n, len(disp_r)))
         if n != 1 or len(disp_r) != 1:
             from mcav.multiscale import multiscale_losses
             return multiscale_losses(tgt_img, ref_imgs, disparity, poses, intrinsics)
         tw = (0.25, 0.25, 0.5)     # mean of the two tgt-view L1 terms and the third term, averaged (losses.py:227-240)
         l0, l1 = _WarpLossFn.apply(disp_t[0].contiguous(), disp_r[0].contiguous(), poses.contiguous(), tgt_img.contiguous(),
-                                   ref_imgs[0].contiguous(), ref_imgs[1].contiguous(), intrinsics.contiguous(), 0, tw)
+                                   ref_imgs[0].contiguous(), ref_imgs[1].contiguous(), intrinsics.contiguous(), ssim_flag, tw)
         return [l0, l1]
 
     def reprojection_loss(self, tgt, refs, depths, poses, intrinsics, mode='min'):
         """Reference signature (losses.py:183): takes DEPTHS (nested [time][scale])."""
         if mode != 'min':
             raise L.MCAVError("reprojection_loss: only mode='min' (the reference's live path) is implemented")
+        ssim_flag = self._flags(len(depths[0]))
         if len(depths[0]) != 1:
             from mcav.multiscale import multiscale_losses
             return multiscale_losses(tgt, refs, depths, poses, intrinsics, inputs_are_depth=True)[0]
         tw = (0.25, 0.25, 0.5)
         l0, _ = _WarpLossFn.apply(depths[0][0].contiguous(), depths[1][0].contiguous(), poses.contiguous(), tgt.contiguous(),
                                   refs[0].contiguous(), refs[1].contiguous(), intrinsics.contiguous(),
-                                  L.WL_INPUT_DEPTH | L.WL_NO_SMOOTH, tw)
+                                  L.WL_INPUT_DEPTH | L.WL_NO_SMOOTH | ssim_flag, tw)
         return l0
 
     def smooth_loss(self, pred_map):

@@ -14,7 +14,7 @@ c_u = ctypes.c_uint
 c_f = ctypes.c_float
 c_sz = ctypes.c_size_t
 
-WL_K_F64, WL_SKIP_IF_UNIT, WL_NO_SMOOTH, WL_INPUT_DEPTH = 1, 2, 4, 8
+WL_K_F64, WL_SKIP_IF_UNIT, WL_NO_SMOOTH, WL_INPUT_DEPTH, WL_SSIM = 1, 2, 4, 8, 16
 
 
 class MCAVError(RuntimeError):

@@ -65,6 +65,7 @@ class Trainer:
             mdist.enable_overlap(self.model_optimizer.arena())      # N > 1: the all-reduce hides behind the rest of backward
 
         self.criterion = Losses()
+        self.criterion.ssim = bool((config.get('loss') or {}).get('ssim', False))     # opt-in SSIM + L1 photometric mix (losses.py)
         from mcav.streams import Branch
         self.pose_branch = Branch()
         self.loss = None
