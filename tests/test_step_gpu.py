@@ -27,22 +27,23 @@ def build_pair(seed_d=141, seed_p=121):
     return hip_d.to(DEV).train(), hip_p.to(DEV).train(), ref_d.train(), ref_p.train()
 
 
-@pytest.mark.parametrize("B,H,W,pair", [(2, 64, 128, False), (3, 96, 160, False), (2, 64, 128, True), (3, 96, 160, True)])
-def test_train_step_vs_oracle(B, H, W, pair):
+@pytest.mark.parametrize("B,H,W,pair,ssim", [(2, 64, 128, False, False), (3, 96, 160, False, False), (2, 64, 128, True, False),
+                                              (3, 96, 160, True, False), (2, 64, 128, True, True)])
+def test_train_step_vs_oracle(B, H, W, pair, ssim):
     from losses import Losses
     from mcav.optim import FusedAdam
     from oracle.step import make_optimizer, synthetic_batch, train_step
     hip_d, hip_p, ref_d, ref_p = build_pair()
     s = synthetic_batch(B, H, W, seed=5)
     ropt = make_optimizer(ref_d, ref_p, 1e-4)
-    (rdisps, rposes), rloss = train_step(ref_d, ref_p, ropt, s)
+    (rdisps, rposes), rloss = train_step(ref_d, ref_p, ropt, s, ssim_weight=0.85 if ssim else 0.0)
 
     opt = FusedAdam(list(hip_d.parameters()) + list(hip_p.parameters()), 1e-4)
     tgt, refs, K = s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], s["intrinsics"].to(DEV)
     opt.zero_grad()
     disps = list(hip_d.forward_pair(tgt, refs[0])) if pair else [hip_d(tgt), hip_d(refs[0])]
     poses = hip_p(tgt, refs)
-    loss = Losses().forward(tgt, refs, disps, poses, K, None)
+    loss = Losses(ssim=ssim).forward(tgt, refs, disps, poses, K, None)
     sum(loss).backward()
     # forward parity: depth maps within 1e-3 relative (north_star), AbsRel reported
     for got, want in zip(disps, rdisps):
@@ -73,6 +74,33 @@ def test_train_step_vs_oracle(B, H, W, pair):
     # BatchNorm running statistics were updated twice (two depth passes), in order
     assert int(hip_d.encoder.encoder.bn1.num_batches_tracked) == 2
     assert rel_err(hip_d.encoder.encoder.bn1.running_var, ref_d.encoder.encoder.bn1.running_var) < 1e-4
+
+
+def test_mixed_resolution_steps_share_no_state():
+    """BASELINE.json configs[4] feeds batches of different resolutions through one process: offset tables, workspaces and packed
+    filters cached for one shape must not leak into the next.  forward+backward at shape A, then B, then A again: bit-identical."""
+    from losses import Losses
+    from oracle.step import synthetic_batch
+    hip_d, hip_p, _, _ = build_pair()
+    params = list(hip_d.parameters()) + list(hip_p.parameters())
+
+    def run(B, H, W, seed):
+        s = synthetic_batch(B, H, W, seed=seed)
+        tgt, refs, K = s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], s["intrinsics"].to(DEV)
+        for p in params:
+            p.grad = None
+        disps = list(hip_d.forward_pair(tgt, refs[0]))
+        loss = Losses().forward(tgt, refs, disps, hip_p(tgt, refs), K, None)
+        sum(loss).backward()
+        torch.cuda.synchronize()
+        return [float(l) for l in loss], [p.grad.clone() for p in params if p.grad is not None]
+
+    la, ga = run(2, 64, 128, 5)
+    lb, _ = run(3, 96, 160, 6)
+    lc, _ = run(1, 128, 416, 7)            # 256x832 / 2
+    la2, ga2 = run(2, 64, 128, 5)
+    assert la == la2 and lb != la and lc != la
+    assert all(torch.equal(x, y) for x, y in zip(ga, ga2))
 
 
 def test_second_step_uses_updated_weights():
