@@ -50,7 +50,7 @@ def measured_traffic(steps_in_profile=3):
 
 
 def synthetic_samples(B, H, W, rank, step=0):
-    from oracle.step import synthetic_batch       # input generator only (shared with the tests)
+    from dataloaders import synthetic_batch
     return synthetic_batch(B, H, W, seed=1234 + 1000 * rank + step)
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timing of the two after-the-step kernels against their HBM roofline, with the CPU oracle beside them.
 
-usage: python tools/post_bench.py     (one JSON line per kernel)
+usage: python tests/post_bench.py     (one JSON line per kernel)
 Algorithmic bytes: metrics = 8 B / pixel (gt + disparity read once); pseudo-LiDAR = 4 B read per pixel twice (count + scatter passes)
 + 32 B written per surviving point.
 """

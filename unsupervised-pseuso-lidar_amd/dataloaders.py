@@ -110,6 +110,18 @@ class SyntheticTriplets(Dataset):
         return {"tgt": imgs[0], "ref_imgs": [imgs[1], imgs[2]], "intrinsics": K, "groundtruth": torch.zeros(1, H, W)}
 
 
+def synthetic_batch(B, H, W, seed=1234):
+    """A whole seeded batch in the collated layout the trainer consumes (bench.py's input): low-passed randn images,
+    KITTI-like fp64 intrinsics as the reference's loader gives them."""
+    g = torch.Generator().manual_seed(seed)
+    imgs = []
+    for _ in range(3):
+        x = torch.randn(B, 3, H, W, generator=g)
+        imgs.append(torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect"), 3, 1).contiguous())
+    K = torch.tensor([[0.58 * W, 0.0, 0.5 * W], [0.0, 1.92 * H, 0.5 * H], [0.0, 0.0, 1.0]], dtype=torch.float64).repeat(B, 1, 1)
+    return {"tgt": imgs[0], "ref_imgs": [imgs[1], imgs[2]], "intrinsics": K, "groundtruth": torch.zeros(B, 1, H, W)}
+
+
 def UnSupKittiDataset(config, transforms=None):
     if config['datasets'].get('dataset', ['KITTI']) == ['synthetic']:
         return SyntheticTriplets(config, transforms)
