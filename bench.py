@@ -151,6 +151,8 @@ def main():
                          "the hipGraph executor of this ROCm serialises the captured branches onto one queue")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="(default) issue every launch eagerly")
     ap.set_defaults(graph=False)
+    ap.add_argument("--serial", action="store_true", help="issue the whole step on ONE stream (for rocprofv3 kernel statistics whose per-kernel "
+                                                          "durations are free of cross-stream overlap; slower than the default three streams)")
     ap.add_argument("--layer-report", default=None, help="write a per-launch table of the instrumented step to this file")
     args = ap.parse_args()
     if os.environ.get("MCAV_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit if the run exceeds N seconds
@@ -172,6 +174,9 @@ def main():
         mdist.enable_overlap(opt.arena())          # N > 1: bucketed all-reduce behind the rest of backward (no-op on one rank)
     s = synthetic_samples(B, H, W, rank)
     samples = {"tgt": s["tgt"].to(device), "ref_imgs": [r.to(device) for r in s["ref_imgs"]], "intrinsics": s["intrinsics"].to(device)}
+    if args.serial:
+        from mcav import streams as _streams
+        _streams.SERIAL = True
     step = make_step(depth, pose, opt, crit, samples, pair=not args.separate_passes, graph=args.graph)
     eager_step = step if not args.graph else make_step(depth, pose, opt, crit, samples, pair=not args.separate_passes, graph=False)
 

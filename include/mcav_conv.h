@@ -150,6 +150,9 @@ int mcav_conv3x3r_c1_bwd(const float* x, int B, int H, int W, int C, const float
 /* NCHW image [B, C, H, W] -> NHWC [B, H, W, Cp] at channel offset choff (other channels untouched; zero the buffer first). */
 int mcav_nchw_to_nhwc(const float* src, int B, int C, int H, int W, float* dst, int Cp, int choff, void* stream);
 int mcav_nhwc_to_nchw(const float* src, int B, int C, int H, int W, int Cp, int choff, float* dst, void* stream);
+/* torch.cat([s0, s1, s2], 1) of three NCHW images (reference pose_net.py:59-61) -> NHWC [B, H, W, Cp], channels past 3 C zeroed: the pose
+ * network's input in one pass.  Cp % 4 == 0, 3 C <= Cp. */
+int mcav_nchw3_to_nhwc(const float* s0, const float* s1, const float* s2, int B, int C, int H, int W, float* dst, int Cp, void* stream);
 
 /* BatchNorm2d, training mode (torchvision BasicBlock/Bottleneck; batch statistics, eps, momentum as nn.BatchNorm2d).
  * finalize: reduce the per-tile column sums written by mcav_igemm into mean / biased variance, produce

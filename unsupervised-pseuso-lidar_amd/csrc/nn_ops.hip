@@ -35,6 +35,34 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* src, in
     }
 }
 
+// The pose network's input: cat(s0, s1, s2) along channels (C planes each) into Cp-channel NHWC pixels, zeros past 3 C.  One lane per
+// 16-byte chunk of a pixel: a wavefront stores 1 KB contiguous, and reads 64-byte runs of each plane.
+__global__ __launch_bounds__(256) void nchw3_to_nhwc_kernel(const float* s0, const float* s1, const float* s2, int B, int C, int H, int W,
+                                                            float* dst, int Cp) {
+    const size_t plane = (size_t)H * W;
+    const int chunks = Cp >> 2;
+    const size_t total = (size_t)B * plane * chunks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / chunks;
+        const int q = (int)(i - p * chunks);
+        const size_t b = p / plane, pix = p - b * plane;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = q * 4 + j;
+            v[j] = 0.f;
+            if (ch < 3 * C) {
+                const int which = ch / C, c = ch - which * C;
+                const float* src = which == 0 ? s0 : (which == 1 ? s1 : s2);
+                v[j] = src[(b * C + c) * plane + pix];
+            }
+        }
+        f32x4 o;
+        o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+        *reinterpret_cast<f32x4*>(dst + i * 4) = o;
+    }
+}
+
 __global__ void nhwc_to_nchw_kernel(const float* src, int B, int C, int H, int W, int Cp, int choff, float* dst) {
     const size_t plane = (size_t)H * W, total = (size_t)B * plane;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -355,6 +383,12 @@ MCAV_EXPORT int mcav_nchw_to_nhwc(const float* src, int B, int C, int H, int W, 
     if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || choff < 0 || choff + C > Cp) return MCAV_E_INVALID;
     if (Cp == 4 && choff == 0) nchw_to_nhwc4_kernel<<<grid_for((size_t)B * H * W), 256, 0, as_stream(stream)>>>(src, B, C, H, W, dst);
     else nchw_to_nhwc_kernel<<<grid_for((size_t)B * H * W), 256, 0, as_stream(stream)>>>(src, B, C, H, W, dst, Cp, choff);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_nchw3_to_nhwc(const float* s0, const float* s1, const float* s2, int B, int C, int H, int W, float* dst, int Cp, void* stream) {
+    if (!s0 || !s1 || !s2 || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (Cp & 3) || 3 * C > Cp) return MCAV_E_INVALID;
+    nchw3_to_nhwc_kernel<<<grid_for((size_t)B * H * W * (Cp >> 2)), 256, 0, as_stream(stream)>>>(s0, s1, s2, B, C, H, W, dst, Cp);
     return launch_status();
 }
 

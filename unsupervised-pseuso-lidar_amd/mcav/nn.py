@@ -46,6 +46,7 @@ L.register({
     "mcav_pack_weights_upmerge_adj": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "mcav_upsample_adj_fold": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
     "mcav_nchw_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "mcav_nchw3_to_nhwc": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "mcav_nhwc_to_nchw": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "mcav_bn_finalize": (c_i, [c_p, c_i, c_i, c_d, c_p, c_p, c_f, c_f] + [c_p] * 6 + [c_i, c_p, c_sz, c_p]),
     "mcav_bn_finalize_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
@@ -574,6 +575,16 @@ def nchw_to_nhwc(src, Cp, dst=None, choff=0):
     if dst is None:
         dst = torch.zeros((B, H, W, Cp), dtype=torch.float32, device=src.device)
     L.check(L.lib().mcav_nchw_to_nhwc(P(src), B, C, H, W, P(dst), Cp, choff, L.stream()), "mcav_nchw_to_nhwc")
+    return dst
+
+
+def nchw3_to_nhwc(s0, s1, s2, Cp):
+    """cat([s0, s1, s2], 1) -> NHWC with Cp channels (zeros past 3 C), one launch."""
+    B, C, H, W = s0.shape
+    if s1.shape != s0.shape or s2.shape != s0.shape:
+        raise L.MCAVError("nchw3_to_nhwc: the three images must have one shape")
+    dst = torch.empty((B, H, W, Cp), dtype=torch.float32, device=s0.device)
+    L.check(L.lib().mcav_nchw3_to_nhwc(P(s0), P(s1), P(s2), B, C, H, W, P(dst), Cp, L.stream()), "mcav_nchw3_to_nhwc")
     return dst
 
 
