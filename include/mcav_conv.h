@@ -147,6 +147,14 @@ int mcav_conv3x3r_c1_bwd(const float* x, int B, int H, int W, int C, const float
                          int x_act, const float* addend, float* dx, float* dw_oihw, float* dbias, int accumulate, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* Measurement hook for bench.py's roofline figure (no reference counterpart).  Between begin() and end() every conv-stage kernel
+ * (implicit-GEMM forward / adjoint, weight gradient, halo and 1-channel stencil kernels; not the packing / reduction helpers) is dispatched
+ * with a start/stop event pair bound to that dispatch.  count(): dispatches recorded so far.  end(): waits for them, writes their durations
+ * in milliseconds, in launch order, to ms[0 .. min(count, capacity)), stops the timer and returns the count (< 0: MCAV_E_*). */
+int mcav_kernel_timer_begin(void);
+int mcav_kernel_timer_count(void);
+int mcav_kernel_timer_end(float* ms, int capacity);
+
 /* NCHW image [B, C, H, W] -> NHWC [B, H, W, Cp] at channel offset choff (other channels untouched; zero the buffer first). */
 int mcav_nchw_to_nhwc(const float* src, int B, int C, int H, int W, float* dst, int Cp, int choff, void* stream);
 int mcav_nhwc_to_nchw(const float* src, int B, int C, int H, int W, int Cp, int choff, float* dst, void* stream);

@@ -11,6 +11,7 @@
 //   * has no K loop, no barrier after the one that publishes the halo, and stores through the usual fused epilogue.
 // v_mfma_f32_16x16x4_f32; a wavefront owns 2 rows x 32 pixels = 4 fragments of 16 consecutive pixels.
 #include "conv_gather.h"
+#include "kernel_timer.h"
 
 namespace mcav {
 
@@ -697,13 +698,13 @@ bool mcav_try_halo(const mcav_igemm_desc* d, hipStream_t s) {
     p.tiles_x = (p.W + HT_W - 1) / HT_W; p.tiles_y = (p.H + HT_H - 1) / HT_H;
     const int grid = p.B * p.tiles_x * p.tiles_y;
 #define HALO_LAUNCH(CC, NN) \
-    do { if (adj) conv3x3_halo_kernel<CC, NN, true><<<grid, 256, 0, s>>>(p); else conv3x3_halo_kernel<CC, NN, false><<<grid, 256, 0, s>>>(p); } while (0)
+    do { if (adj) timed_launch(conv3x3_halo_kernel<CC, NN, true>, grid, dim3(256), 0, s, p); else timed_launch(conv3x3_halo_kernel<CC, NN, false>, grid, dim3(256), 0, s, p); } while (0)
     // upsampled source + reflection padding: 4 merged taps on the low-resolution map (desc.tile bit 10 keeps the 9-tap kernel)
     if (!adj && d->up1 && d->pad_mode == MCAV_PAD_REFLECT && !(d->Hs & 1) && !(d->Ws & 1) && !((d->tile >> 10) & 1)) {
         for (p.co0 = 0; p.co0 < d->n_count; p.co0 += 16 * nf) {
-            if (d->C1 == 16 && nf == 1) conv3x3_halo_up_kernel<16, 1><<<grid, 256, 0, s>>>(p);
-            else if (d->C1 == 16) conv3x3_halo_up_kernel<16, 2><<<grid, 256, 0, s>>>(p);
-            else conv3x3_halo_up_kernel<32, 1><<<grid, 256, 0, s>>>(p);
+            if (d->C1 == 16 && nf == 1) timed_launch(conv3x3_halo_up_kernel<16, 1>, grid, dim3(256), 0, s, p);
+            else if (d->C1 == 16) timed_launch(conv3x3_halo_up_kernel<16, 2>, grid, dim3(256), 0, s, p);
+            else timed_launch(conv3x3_halo_up_kernel<32, 1>, grid, dim3(256), 0, s, p);
         }
         return true;
     }
@@ -736,8 +737,8 @@ void mcav_halo_wgrad_launch(const mcav_wgrad_desc* d, float* slab, int slabN, in
     p.slab = slab; p.slabN = slabN; p.Ktot = 9 * d->Kp; p.want_bias = d->dbias != nullptr;
     p.tiles_x = (p.W + HT_W - 1) / HT_W; p.tiles_y = (p.H + HT_H - 1) / HT_H; p.tiles = p.B * p.tiles_x * p.tiles_y;
     if (p.up && p.pad_mode == MCAV_PAD_REFLECT && !(p.H & 1) && !(p.W & 1) && d->C1 == 16 && d->Cout <= 16 && !((d->tile >> 10) & 1))
-        conv3x3_halo_wgrad_up_kernel<16, 1><<<splits, 256, 0, s>>>(p);
-    else if (d->C1 == 16 && d->Cout <= 16) conv3x3_halo_wgrad_kernel<16, 1><<<splits, 256, 0, s>>>(p);
-    else if (d->C1 == 16) conv3x3_halo_wgrad_kernel<16, 2><<<splits, 256, 0, s>>>(p);
-    else conv3x3_halo_wgrad_kernel<32, 1><<<splits, 256, 0, s>>>(p);
+        timed_launch(conv3x3_halo_wgrad_up_kernel<16, 1>, dim3(splits), dim3(256), 0, s, p);
+    else if (d->C1 == 16 && d->Cout <= 16) timed_launch(conv3x3_halo_wgrad_kernel<16, 1>, dim3(splits), dim3(256), 0, s, p);
+    else if (d->C1 == 16) timed_launch(conv3x3_halo_wgrad_kernel<16, 2>, dim3(splits), dim3(256), 0, s, p);
+    else timed_launch(conv3x3_halo_wgrad_kernel<32, 1>, dim3(splits), dim3(256), 0, s, p);
 }

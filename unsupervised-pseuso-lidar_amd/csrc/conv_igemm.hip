@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "conv_gather.h"
+#include "kernel_timer.h"
 
 namespace mcav {
 
@@ -1638,12 +1639,12 @@ inline void launch_igemm(const IgemmParams& p, hipStream_t s) {
     // (tall tiles put rows of many image lines into one wavefront: most wavefronts would take the border path, so they keep the general kernel)
     const bool tab_refl = p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0 && p.g.C1 == p.Kp && p.Kp % T::KD == 0 && !p.no_tab && T::AROWS <= 2;
     const size_t tab_bytes = sizeof(unsigned) * (size_t)p.taps * T::BM * (p.g.C2 > 0 ? 2 : 1);
-    if (p.upm) igemm_tab_kernel<T, 2><<<grid, 256, sizeof(unsigned) * 13 * T::BM, s>>>(p);
-    else if (tab) igemm_tab_kernel<T, 0><<<grid, 256, tab_bytes, s>>>(p);
-    else if (tab_refl) igemm_tab_kernel<T, 1><<<grid, 256, tab_bytes, s>>>(p);
-    else if (fast_mode && c4ok) igemm_kernel<T, K_FAST><<<grid, 256, 0, s>>>(p);
-    else if (p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0) igemm_kernel<T, K_REFLADJ><<<grid, 256, 0, s>>>(p);
-    else igemm_kernel<T, K_GENERIC><<<grid, 256, 0, s>>>(p);
+    if (p.upm) timed_launch(igemm_tab_kernel<T, 2>, grid, dim3(256), sizeof(unsigned) * 13 * T::BM, s, p);
+    else if (tab) timed_launch(igemm_tab_kernel<T, 0>, grid, dim3(256), tab_bytes, s, p);
+    else if (tab_refl) timed_launch(igemm_tab_kernel<T, 1>, grid, dim3(256), tab_bytes, s, p);
+    else if (fast_mode && c4ok) timed_launch(igemm_kernel<T, K_FAST>, grid, dim3(256), 0, s, p);
+    else if (p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0) timed_launch(igemm_kernel<T, K_REFLADJ>, grid, dim3(256), 0, s, p);
+    else timed_launch(igemm_kernel<T, K_GENERIC>, grid, dim3(256), 0, s, p);
 }
 
 }  // namespace mcav
@@ -1796,13 +1797,13 @@ inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
 template <class T>
 inline void launch_wgrad(const WgradParams& p, bool use_tab, hipStream_t s) {
     const int grid = p.splits * p.mtiles * p.ntiles;
-    if (use_tab && p.upm) { wgrad_tab_kernel<T, true><<<grid, 256, 0, s>>>(p); return; }
-    if (use_tab) { wgrad_tab_kernel<T, false><<<grid, 256, 0, s>>>(p); return; }
+    if (use_tab && p.upm) { timed_launch(wgrad_tab_kernel<T, true>, grid, dim3(256), 0, s, p); return; }
+    if (use_tab) { timed_launch(wgrad_tab_kernel<T, false>, grid, dim3(256), 0, s, p); return; }
     const int wave_ch = T::BM / 4;          // channels one wavefront's A columns span
     const bool fast = (p.g.mode == MCAV_G_DIRECT || p.g.mode == MCAV_G_SMALLC) && (p.g.C1 & 3) == 0 && (p.g.C2 & 3) == 0 && (p.g.C2 == 0 || p.g.C1 % wave_ch == 0) &&
                       (p.CoutLoad & 3) == 0 && (p.Cdy & 3) == 0 && (p.dy_choff & 3) == 0 && p.Wd >= 16;
-    if (fast) wgrad_kernel<T, K_FAST><<<grid, 256, 0, s>>>(p);
-    else wgrad_kernel<T, K_GENERIC><<<grid, 256, 0, s>>>(p);
+    if (fast) timed_launch(wgrad_kernel<T, K_FAST>, grid, dim3(256), 0, s, p);
+    else timed_launch(wgrad_kernel<T, K_GENERIC>, grid, dim3(256), 0, s, p);
 }
 
 }  // namespace mcav

@@ -13,6 +13,7 @@
 //             (x is read once, 64 B per pixel; the generic path read it 9 times for wgrad and again for dgrad).
 // Reductions: lane accumulators -> wavefront shuffles -> LDS -> per-block slab -> fixed-order finalize (no atomics).
 #include "conv_gather.h"
+#include "kernel_timer.h"
 
 namespace mcav {
 
@@ -196,10 +197,10 @@ MCAV_EXPORT int mcav_conv3x3r_c1_fwd(const float* x, int B, int H, int W, int C,
     long blocks = (npix + ppb - 1) / ppb;
     if (blocks > 8192) blocks = 8192;
     switch (C) {
-        case 16: conv3x3r_c1_fwd_kernel<4><<<(int)blocks, 256, 0, s>>>(x, B, H, W, w_oihw, bias, act, y); break;
-        case 32: conv3x3r_c1_fwd_kernel<8><<<(int)blocks, 256, 0, s>>>(x, B, H, W, w_oihw, bias, act, y); break;
-        case 64: conv3x3r_c1_fwd_kernel<16><<<(int)blocks, 256, 0, s>>>(x, B, H, W, w_oihw, bias, act, y); break;
-        default: conv3x3r_c1_fwd_kernel<32><<<(int)blocks, 256, 0, s>>>(x, B, H, W, w_oihw, bias, act, y); break;
+        case 16: timed_launch(conv3x3r_c1_fwd_kernel<4>, dim3((int)blocks), dim3(256), 0, s, x, B, H, W, w_oihw, bias, act, y); break;
+        case 32: timed_launch(conv3x3r_c1_fwd_kernel<8>, dim3((int)blocks), dim3(256), 0, s, x, B, H, W, w_oihw, bias, act, y); break;
+        case 64: timed_launch(conv3x3r_c1_fwd_kernel<16>, dim3((int)blocks), dim3(256), 0, s, x, B, H, W, w_oihw, bias, act, y); break;
+        default: timed_launch(conv3x3r_c1_fwd_kernel<32>, dim3((int)blocks), dim3(256), 0, s, x, B, H, W, w_oihw, bias, act, y); break;
     }
     return launch_status();
 }
@@ -222,10 +223,10 @@ MCAV_EXPORT int mcav_conv3x3r_c1_bwd(const float* x, int B, int H, int W, int C,
     if (blocks > NC_BWD_BLOCKS) blocks = NC_BWD_BLOCKS;
     float* slab = reinterpret_cast<float*>(workspace);
     switch (C) {
-        case 16: conv3x3r_c1_bwd_kernel<4><<<(int)blocks, 256, 0, s>>>(x, B, H, W, w_oihw, dy, y, act, x_act, addend, dx, slab); break;
-        case 32: conv3x3r_c1_bwd_kernel<8><<<(int)blocks, 256, 0, s>>>(x, B, H, W, w_oihw, dy, y, act, x_act, addend, dx, slab); break;
-        case 64: conv3x3r_c1_bwd_kernel<16><<<(int)blocks, 256, 0, s>>>(x, B, H, W, w_oihw, dy, y, act, x_act, addend, dx, slab); break;
-        default: conv3x3r_c1_bwd_kernel<32><<<(int)blocks, 256, 0, s>>>(x, B, H, W, w_oihw, dy, y, act, x_act, addend, dx, slab); break;
+        case 16: timed_launch(conv3x3r_c1_bwd_kernel<4>, dim3((int)blocks), dim3(256), 0, s, x, B, H, W, w_oihw, dy, y, act, x_act, addend, dx, slab); break;
+        case 32: timed_launch(conv3x3r_c1_bwd_kernel<8>, dim3((int)blocks), dim3(256), 0, s, x, B, H, W, w_oihw, dy, y, act, x_act, addend, dx, slab); break;
+        case 64: timed_launch(conv3x3r_c1_bwd_kernel<16>, dim3((int)blocks), dim3(256), 0, s, x, B, H, W, w_oihw, dy, y, act, x_act, addend, dx, slab); break;
+        default: timed_launch(conv3x3r_c1_bwd_kernel<32>, dim3((int)blocks), dim3(256), 0, s, x, B, H, W, w_oihw, dy, y, act, x_act, addend, dx, slab); break;
     }
     conv3x3r_c1_finalize_kernel<<<9 * C + 1, 256, 0, s>>>(slab, (int)blocks, C, dw_oihw, dbias, accumulate);
     return launch_status();

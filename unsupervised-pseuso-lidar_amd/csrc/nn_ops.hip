@@ -542,3 +542,51 @@ MCAV_EXPORT int mcav_adam_step(float* param, const float* grad, float* exp_avg, 
                                                                        (float)sqrt(bc2), grad_scale);
     return launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------- conv-kernel timer (kernel_timer.h)
+#include <mutex>
+#include <vector>
+
+#include "kernel_timer.h"
+
+namespace mcav {
+static std::mutex g_kt_mutex;                       // forward launches come from the caller's thread, backward ones from autograd's
+static bool g_kt_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_kt_events;
+
+bool kernel_timer_on() { return g_kt_on; }
+void kernel_timer_add(hipEvent_t e0, hipEvent_t e1) {
+    std::lock_guard<std::mutex> lock(g_kt_mutex);
+    g_kt_events.emplace_back(e0, e1);
+}
+}  // namespace mcav
+
+MCAV_EXPORT int mcav_kernel_timer_begin(void) {
+    std::lock_guard<std::mutex> lock(mcav::g_kt_mutex);
+    for (auto& e : mcav::g_kt_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    mcav::g_kt_events.clear();
+    mcav::g_kt_on = true;
+    return MCAV_OK;
+}
+
+MCAV_EXPORT int mcav_kernel_timer_count(void) {
+    std::lock_guard<std::mutex> lock(mcav::g_kt_mutex);
+    return (int)mcav::g_kt_events.size();
+}
+
+MCAV_EXPORT int mcav_kernel_timer_end(float* ms, int capacity) {
+    std::lock_guard<std::mutex> lock(mcav::g_kt_mutex);
+    mcav::g_kt_on = false;
+    const int n = (int)mcav::g_kt_events.size();
+    int rc = MCAV_OK;
+    for (int i = 0; i < n; ++i) {
+        auto& e = mcav::g_kt_events[i];
+        float t = 0.f;
+        if (hipEventSynchronize(e.second) != hipSuccess || hipEventElapsedTime(&t, e.first, e.second) != hipSuccess) rc = MCAV_E_LAUNCH;
+        if (ms && i < capacity) ms[i] = t;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    mcav::g_kt_events.clear();
+    return rc == MCAV_OK ? n : rc;
+}

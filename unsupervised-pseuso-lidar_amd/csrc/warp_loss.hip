@@ -8,6 +8,7 @@
 // L1/L2 (neighbouring pixels sample neighbouring source texels), deterministic two-level reduction
 // (wavefront shuffles -> LDS -> per-block slab -> fp64 finalize) for the 2 loss scalars and the 3x12 dP sums.
 #include "mcav_common.h"
+#include "kernel_timer.h"
 #include "warp_math.h"
 
 namespace mcav {
@@ -702,7 +703,7 @@ MCAV_EXPORT int mcav_warp_loss_fwd_bwd(const float* tgt, const float* ref0, cons
     double* sl = reinterpret_cast<double*>(ws + l.sl_off);
     hipStream_t s = as_stream(stream);
     const float* up = upstream ? upstream : ones;
-    pose_prepare_kernel<<<(B + 63) / 64, 64, 0, s>>>(poses, K, nullptr, B, 0, 0, (flags & MCAV_WL_K_F64) ? 1 : 0, pc, ones);
+    timed_launch(pose_prepare_kernel, dim3((B + 63) / 64), dim3(64), 0, s, poses, K, (const float*)nullptr, B, 0, 0, (flags & MCAV_WL_K_F64) ? 1 : 0, pc, ones);
     WLArgs a;
     a.tgt = tgt; a.ref0 = ref0; a.ref1 = ref1; a.disp_t = disp_t; a.disp_r0 = disp_r0; a.poses = poses;
     a.upstream = up; a.d_disp_t = d_disp_t; a.d_disp_r0 = d_disp_r0; a.pc = pc; a.slab = slab;
@@ -711,9 +712,10 @@ MCAV_EXPORT int mcav_warp_loss_fwd_bwd(const float* tgt, const float* ref0, cons
     a.tw[1] = term_weights ? term_weights[1] : 0.25f;
     a.tw[2] = term_weights ? term_weights[2] : 0.5f;
     const dim3 wl_grid((W + TW - 1) / TW, (H + WLH - 1) / WLH, B);
-    if (flags & MCAV_WL_SSIM) warp_loss_ssim_kernel<<<wl_grid, 256, 0, s>>>(a);
-    else warp_loss_kernel<<<wl_grid, 256, 0, s>>>(a);
-    warp_loss_finalize_kernel<<<B, 1024, 0, s>>>(slab, (int)(wl_grid.x * wl_grid.y), pc, poses, up, flags, d_poses, sl, reinterpret_cast<unsigned*>(ones) + 2, B, losses);
+    if (flags & MCAV_WL_SSIM) timed_launch(warp_loss_ssim_kernel, wl_grid, dim3(256), 0, s, a);
+    else timed_launch(warp_loss_kernel, wl_grid, dim3(256), 0, s, a);
+    timed_launch(warp_loss_finalize_kernel, dim3(B), dim3(1024), 0, s, (const float*)slab, (int)(wl_grid.x * wl_grid.y), (const PrepConst*)pc, poses, up, flags,
+                 d_poses, sl, reinterpret_cast<unsigned*>(ones) + 2, B, losses);
     return launch_status();
 }
 

@@ -66,10 +66,28 @@ L.register({
     "mcav_spatial_mean": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "mcav_spatial_mean_bwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "mcav_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_sz, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
+    "mcav_kernel_timer_begin": (c_i, []),
+    "mcav_kernel_timer_count": (c_i, []),
+    "mcav_kernel_timer_end": (c_i, [c_p, c_i]),
 })
 
 
-# bench.py's instrumented step: when PROFILE is a list every conv launch is bracketed by events on the launch stream
+def kernel_timer_begin():
+    L.check(L.lib().mcav_kernel_timer_begin(), "mcav_kernel_timer_begin")
+
+
+def kernel_timer_end():
+    """-> per-dispatch durations (ms) of the conv kernels launched since kernel_timer_begin(), in launch order."""
+    n = L.lib().mcav_kernel_timer_count()
+    buf = (ctypes.c_float * max(1, n))()
+    got = L.lib().mcav_kernel_timer_end(buf, n)
+    if got < 0:
+        L.check(got, "mcav_kernel_timer_end")
+    return [float(buf[i]) for i in range(min(n, got))]
+
+
+# bench.py's instrumented step: when PROFILE is a list (and mcav_kernel_timer_begin() was called) every conv kernel is dispatched with its
+# own start/stop event pair inside the library (csrc/kernel_timer.h); a record notes which of those dispatches a call issued
 PROFILE = None
 PROFILE_LOSS = None
 PROFILE_TAGS = None
@@ -81,15 +99,12 @@ class _Timed:
 
     def __enter__(self):
         if PROFILE is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
+            self.i0 = L.lib().mcav_kernel_timer_count()
         return self
 
     def __exit__(self, *exc):
         if PROFILE is not None:
-            self.e1.record()
-            PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+            PROFILE.append((self.kind, self.flops, self.i0, L.lib().mcav_kernel_timer_count()))
             if PROFILE_TAGS is not None:
                 PROFILE_TAGS.append(self.tag)
         return False
