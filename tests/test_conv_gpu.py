@@ -332,3 +332,44 @@ def test_multi_pack_matches_single_pack():
         assert torch.equal(s.packed_fwd(), f)
         if b is not None:
             assert torch.equal(s.packed_bwd(), b)
+
+
+def test_pose_input_pack_is_cat_in_nhwc():
+    """mcav_nchw3_to_nhwc == torch.cat([tgt, ref0, ref1], 1) laid out NHWC in 16 channels, zeros past the ninth (pose_net.py:59-61)."""
+    from mcav import nn as N
+    g = torch.Generator().manual_seed(9)
+    for B, H, W in ((2, 5, 7), (3, 64, 96)):
+        imgs = [torch.randn(B, 3, H, W, generator=g).to(DEV) for _ in range(3)]
+        got = N.nchw3_to_nhwc(*imgs, 16)
+        want = torch.zeros(B, H, W, 16, device=DEV)
+        want[..., :9] = torch.cat(imgs, 1).permute(0, 2, 3, 1)
+        assert torch.equal(got, want)
+    with pytest.raises(Exception):
+        N.nchw3_to_nhwc(imgs[0], imgs[1], imgs[2][:, :, :-1], 16)
+
+
+def test_kernel_timer_counts_conv_dispatches():
+    """bench.py's roofline hook: between begin() and end() every conv kernel is timed per dispatch; results are unchanged and the
+    timer is off again afterwards."""
+    from mcav import nn as N
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 32, 24, 40, generator=g)
+    wt = torch.randn(32, 32, 3, 3, generator=g) * 0.05
+    conv = torch.nn.Conv2d(32, 32, 3, padding=1, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(wt)
+    conv = conv.to(DEV)
+    spec = N.ConvSpec(conv.weight, conv.bias, 1, 1, N.PAD_ZERO)
+    xd = nhwc(x)
+    y0 = N.conv_fwd(spec, xd)
+    assert N.L.lib().mcav_kernel_timer_count() == 0
+    N.kernel_timer_begin()
+    y1 = N.conv_fwd(spec, xd)
+    k = N.L.lib().mcav_kernel_timer_count()           # dispatches of one convolution (the halo kernel runs in blocks of 16 channels)
+    y2 = N.conv_fwd(spec, xd)
+    assert k >= 1 and N.L.lib().mcav_kernel_timer_count() == 2 * k
+    durs = N.kernel_timer_end()
+    assert len(durs) == 2 * k and all(0.0 < d < 50.0 for d in durs)
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)
+    N.conv_fwd(spec, xd)
+    assert N.L.lib().mcav_kernel_timer_count() == 0
