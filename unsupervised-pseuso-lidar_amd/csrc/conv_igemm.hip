@@ -1317,8 +1317,11 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
     };
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
-    f32x4 ra[APASS], rb[BPASS];
-    auto step = [&](auto cur, auto nxt) {
+    // Two register stages: while tile t is multiplied, tile t + 1 moves from registers to the other LDS buffer and the loads of tiles
+    // t + 2 and t + 3 are in flight -- a load has two MFMA phases (of this wavefront alone) to land, not one.  Stage s holds the tiles of
+    // parity s.
+    f32x4 ra0[APASS], rb0[BPASS], ra1[APASS], rb1[BPASS];
+    auto step = [&](auto cur, auto nxt, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {      // (ra, rb): the stage of tiles t + 1 and t + 3
         store(ra, rb, nxt);
         issue(ra, rb);
         __builtin_amdgcn_sched_barrier(0);
@@ -1329,28 +1332,31 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
     int t = 0;
     if (T_total > 0) {
         fetch();
-        issue(ra, rb);
-        store(ra, rb, B0{});
-        if (T_total > 1) issue(ra, rb);
+        issue(ra0, rb0);
+        store(ra0, rb0, B0{});
+        if (T_total > 1) issue(ra1, rb1);
+        if (T_total > 2) issue(ra0, rb0);
     }
     __syncthreads();
-    // Chunk c + 1 is computed when the compute pointer enters chunk c: its half-buffer held chunk c - 1, whose last entry was
-    // fetched three steps ago, and its first entry is fetched no earlier than the next step (CHT >= 4) -- barriers on both sides.
-    auto maybe_build = [&]() {
-        if (t > 0 && (t & ((1 << cht) - 1)) == 0 && (t >> cht) + 1 < nchunks) build_chunk((t >> cht) + 1);
+    // Chunk c + 1 is computed one step before the compute pointer enters chunk c: its half-buffer held chunk c - 1, whose last entry was
+    // fetched five steps ago, and its first entry (tile (c + 1) CHT, fetched while tile (c + 1) CHT - 4 is computed) is fetched no earlier
+    // than the next step (CHT >= 4) -- barriers on both sides.
+    auto maybe_build = [&](int tt) {
+        if (((tt + 1) & ((1 << cht) - 1)) == 0 && ((tt + 1) >> cht) + 1 < nchunks) build_chunk(((tt + 1) >> cht) + 1);
     };
-    for (; t + 3 < T_total; t += 2) {
-        maybe_build();
-        step(B0{}, B1{});
-        step(B1{}, B0{});
+    for (; t + 4 < T_total; t += 2) {
+        maybe_build(t);
+        step(B0{}, B1{}, ra1, rb1);
+        maybe_build(t + 1);
+        step(B1{}, B0{}, ra0, rb0);
     }
     for (; t < T_total; ++t) {
-        maybe_build();
+        maybe_build(t);
         if (t & 1) {
-            if (t + 1 < T_total) { store(ra, rb, B0{}); if (t + 2 < T_total) issue(ra, rb); }
+            if (t + 1 < T_total) { store(ra0, rb0, B0{}); if (t + 3 < T_total) issue(ra0, rb0); }
             compute(B1{});
         } else {
-            if (t + 1 < T_total) { store(ra, rb, B1{}); if (t + 2 < T_total) issue(ra, rb); }
+            if (t + 1 < T_total) { store(ra1, rb1, B1{}); if (t + 3 < T_total) issue(ra1, rb1); }
             compute(B0{});
         }
         __syncthreads();
