@@ -1140,6 +1140,13 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
     constexpr int ACOLS = BM / 4, APIX = 256 / ACOLS, APASS = KP / APIX, CPW = ACOLS / 4;
     const int acol = wave * CPW + lane % CPW, apix = lane / CPW;
     const int kflat = m0 + acol * 4;
+    // Xs rows are BM floats: with BM = 64 two consecutive pixels start on the same bank, and both an 8-lane ds_write_b128 group (two
+    // pixels x four 16-byte columns) and a 32-lane read group of the 16-wide MFMA (two pixels x 16 rows) would be 2-way conflicts.
+    // Odd pixels therefore store their row with the two 16-float halves of every 32 swapped (column ^ 16); pixel parity is a per-lane
+    // constant on both sides (APIX and KSTEP are even), so the swizzle costs no instruction in the loop.
+    constexpr bool XSWZ = BM == 64;
+    const int xswz_w = XSWZ ? (apix & 1) << 4 : 0;
+    const int xswz_r = XSWZ ? ((lane / T::MF) & 1) << 4 : 0;
     constexpr int BCOLS = BN / 4;
     constexpr int BPIX = 256 / BCOLS > KP ? KP : 256 / BCOLS;
     constexpr int BPASS = KP / BPIX;
@@ -1265,7 +1272,7 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
             for (int j = 0; j < BPASS; ++j) bsum += rb[j];
         }
 #pragma unroll
-        for (int j = 0; j < APASS; ++j) *reinterpret_cast<f32x4*>(&Xs[buf][apix + j * APIX][acol * 4]) = ra[j];
+        for (int j = 0; j < APASS; ++j) *reinterpret_cast<f32x4*>(&Xs[buf][apix + j * APIX][(acol * 4) ^ xswz_w]) = ra[j];
 #pragma unroll
         for (int j = 0; j < BPASS; ++j) {
             const int pl = bpix + j * BPIX;
@@ -1293,7 +1300,7 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int i = 0; i < T::TM; ++i) a[s][q][i] = Xs[buf][(k0 + q) * KSTEP + fk][wm0 + i * MFR + fr];
+                for (int i = 0; i < T::TM; ++i) a[s][q][i] = Xs[buf][(k0 + q) * KSTEP + fk][(wm0 + i * MFR + fr) ^ xswz_r];
 #pragma unroll
                 for (int j = 0; j < T::TN; ++j) b[s][q][j] = Ys[buf][(k0 + q) * KSTEP + fk][wn0 + j * MFR + fr];
             }
