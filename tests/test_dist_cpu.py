@@ -35,7 +35,7 @@ def _worker(rank, world, port, out):
     params[1].grad.fill_(10.0 * (rank + 1))
     scale = mdist.allreduce_gradients(a)
     idx = mdist.shard_indices(list(range(11)))
-    out.put((rank, a.flat.clone(), a.gflat.clone(), scale, idx))
+    out.put((rank, a.flat.tolist(), a.gflat.tolist(), scale, idx))      # plain lists: a tensor in the queue is a handle the exiting worker takes with it
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,8 +52,8 @@ def test_two_rank_gloo_allreduce_and_sharding():
         p.join(60)
         assert p.exitcode == 0
     (_, f0, g0, s0, i0), (_, f1, g1, s1, i1) = res
-    assert torch.equal(f0, f1)                              # parameters broadcast from rank 0
-    assert torch.equal(g0, g1) and s0 == s1 == 0.5          # summed gradients, 1/world for Adam
+    assert f0 == f1                                         # parameters broadcast from rank 0
+    assert g0 == g1 and s0 == s1 == 0.5                     # summed gradients, 1/world for Adam
     assert float(g0[0]) == 3.0 and float(g0[16]) == 30.0    # 1+2 and 10+20 (second tensor starts at the 16-float slot)
     assert i0 == [0, 1, 2, 3, 4] and i1 == [5, 6, 7, 8, 9]  # disjoint equal slices, remainder dropped
 
@@ -81,7 +81,7 @@ def _worker_overlap(rank, world, port, out):
         N.grads_ready([params[0], params[5]])              # not contiguous: ignored, left to finish()
         N.grads_ready(params[2:4])                         # overlaps ranges already in flight: ignored
         scale = mdist.allreduce_gradients(a)
-        results.append(a.gflat.clone())
+        results.append(a.gflat.tolist())
     out.put((rank, results, scale))
     dist.barrier()
     dist.destroy_process_group()
@@ -100,8 +100,8 @@ def test_two_rank_bucketed_overlap_equals_one_allreduce():
         assert p.exitcode == 0
     (_, r0, s0), (_, r1, s1) = res
     assert s0 == s1 == 0.5
-    numel = r0[0].numel()
+    numel = len(r0[0])
     for step in range(2):
         want = sum(torch.randn(numel, generator=torch.Generator().manual_seed(1000 * step + r)) for r in range(2))
-        assert torch.equal(r0[step], r1[step])
-        assert torch.allclose(r0[step], want, rtol=0, atol=0)      # every element summed exactly once
+        assert r0[step] == r1[step]
+        assert torch.equal(torch.tensor(r0[step]), want)           # every element summed exactly once
