@@ -1292,33 +1292,35 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
     constexpr int MFR = T::MF;
     constexpr int KSTEP = MFR == 32 ? 2 : 4;              // pixels consumed per MFMA
     const int fr = lane & (MFR - 1), fk = lane / MFR;
-    auto compute = [&](auto bufc) {
+    constexpr int NB = KP / KSTEP / 4;                    // batches of 4 MFMA k-steps; batch b + 1 is read before batch b is issued
+    float a[2][4][T::TM], b[2][4][T::TN];
+    auto rd = [&](auto bufc, int s, int k0) {
         constexpr int buf = decltype(bufc)::value;
-        constexpr int NB = KP / KSTEP / 4;                // batches of 4 MFMA k-steps; batch b + 1 is read before batch b is issued
-        float a[2][4][T::TM], b[2][4][T::TN];
-        auto rd = [&](int s, int k0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int i = 0; i < T::TM; ++i) a[s][q][i] = Xs[buf][(k0 + q) * KSTEP + fk][(wm0 + i * MFR + fr) ^ xswz_r];
+            for (int i = 0; i < T::TM; ++i) a[s][q][i] = Xs[buf][(k0 + q) * KSTEP + fk][(wm0 + i * MFR + fr) ^ xswz_r];
 #pragma unroll
-                for (int j = 0; j < T::TN; ++j) b[s][q][j] = Ys[buf][(k0 + q) * KSTEP + fk][wn0 + j * MFR + fr];
+            for (int j = 0; j < T::TN; ++j) b[s][q][j] = Ys[buf][(k0 + q) * KSTEP + fk][wn0 + j * MFR + fr];
+        }
+    };
+    auto mma = [&](int s, int q) {
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j) {
+                if constexpr (MFR == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][q][i], b[s][q][j], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][q][i], b[s][q][j], acc[i][j], 0, 0, 0);
             }
-        };
-        rd(0, 0);
+    };
+    auto compute = [&](auto bufc) {
+        rd(bufc, 0, 0);
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) {
-            if (bt + 1 < NB) rd((bt + 1) & 1, (bt + 1) * 4);
+            if (bt + 1 < NB) rd(bufc, (bt + 1) & 1, (bt + 1) * 4);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < T::TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < T::TN; ++j) {
-                        if constexpr (MFR == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[bt & 1][q][i], b[bt & 1][q][j], acc[i][j], 0, 0, 0);
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[bt & 1][q][i], b[bt & 1][q][j], acc[i][j], 0, 0, 0);
-                    }
+            for (int q = 0; q < 4; ++q) mma(bt & 1, q);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -1328,12 +1330,68 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
     // t + 2 and t + 3 are in flight -- a load has two MFMA phases (of this wavefront alone) to land, not one.  Stage s holds the tiles of
     // parity s.
     f32x4 ra0[APASS], rb0[BPASS], ra1[APASS], rb1[BPASS];
+    // Steady-state step.  A wavefront issues in order and its MFMAs form one dependent chain (64 cycles apart), so everything else of
+    // the step -- the LDS stores of tile t + 1, the global loads of tile t + 3, the table fetch -- is cut into pieces and one piece is
+    // placed behind each MFMA, where it issues while the MFMA pipe works, instead of in a block of its own in front of the MFMAs.
+    constexpr int NSLOT = NB * 4;                         // MFMA k-steps of a tile = slots for pieces
+    constexpr int NPIECE = 2 * APASS + 2 * BPASS + 1;     // A stores, B stores, A loads, B loads, advance
+    auto piece = [&](auto pc, auto nxt, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
+        constexpr int P = decltype(pc)::value, buf = decltype(nxt)::value;
+        if constexpr (P < APASS) {
+            *reinterpret_cast<f32x4*>(&Xs[buf][apix + P * APIX][(acol * 4) ^ xswz_w]) = ra[P];
+        } else if constexpr (P < APASS + BPASS) {
+            constexpr int j = P - APASS;
+            if (do_bias) bsum += rb[j];
+            const int pl = bpix + j * BPIX;
+            if (256 / BCOLS <= KP || pl < KP) *reinterpret_cast<f32x4*>(&Ys[buf][pl][bcol * 4]) = rb[j];
+        } else if constexpr (P < 2 * APASS + BPASS) {
+            constexpr int j = P - APASS - BPASS;
+            ra[j] = buf_load4(rsx, toff[j] + chan);
+        } else if constexpr (P < 2 * APASS + 2 * BPASS) {
+            constexpr int j = P - 2 * APASS - BPASS;
+            if constexpr (UPM) rb[j] = buf_load4(rsy, ((tboff[j] | boff[j]) & OOB) ? OOB : tboff[j] + boff[j]);
+            else rb[j] = buf_load4s(rsy, boff[j], u * KP * p.Cdy * 4);
+        } else {
+            ++u;
+            if (u < T_total) fetch();
+        }
+    };
+    auto pieces_of_slot = [&](auto sc, auto nxt, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
+        constexpr int S = decltype(sc)::value;
+        constexpr int lo = S * NPIECE / NSLOT, hi = (S + 1) * NPIECE / NSLOT;
+        if constexpr (lo < hi) {
+            piece(std::integral_constant<int, lo>{}, nxt, ra, rb);
+            if constexpr (lo + 1 < hi) piece(std::integral_constant<int, lo + 1>{}, nxt, ra, rb);
+            if constexpr (lo + 2 < hi) piece(std::integral_constant<int, lo + 2>{}, nxt, ra, rb);
+        }
+        static_assert(hi - lo <= 3, "at most three pieces per MFMA slot");
+    };
+    auto slot = [&](auto sc, auto nxt, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
+        constexpr int S = decltype(sc)::value;
+        mma((S >> 2) & 1, S & 3);
+        __builtin_amdgcn_sched_barrier(0);
+        pieces_of_slot(sc, nxt, ra, rb);
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto step = [&](auto cur, auto nxt, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {      // (ra, rb): the stage of tiles t + 1 and t + 3
-        store(ra, rb, nxt);
-        issue(ra, rb);
+        rd(cur, 0, 0);
+        static_assert(NB == 2 || NB == 4, "two or four operand batches per tile");
+        if constexpr (NB > 1) rd(cur, 1, 4);
         __builtin_amdgcn_sched_barrier(0);
-        compute(cur);
+        slot(std::integral_constant<int, 0>{}, nxt, ra, rb); slot(std::integral_constant<int, 1>{}, nxt, ra, rb);
+        slot(std::integral_constant<int, 2>{}, nxt, ra, rb); slot(std::integral_constant<int, 3>{}, nxt, ra, rb);
+        if constexpr (NB > 2) rd(cur, 0, 8);
         __builtin_amdgcn_sched_barrier(0);
+        slot(std::integral_constant<int, 4>{}, nxt, ra, rb); slot(std::integral_constant<int, 5>{}, nxt, ra, rb);
+        slot(std::integral_constant<int, 6>{}, nxt, ra, rb); slot(std::integral_constant<int, 7>{}, nxt, ra, rb);
+        if constexpr (NB > 2) {
+            rd(cur, 1, 12);
+            __builtin_amdgcn_sched_barrier(0);
+            slot(std::integral_constant<int, 8>{}, nxt, ra, rb); slot(std::integral_constant<int, 9>{}, nxt, ra, rb);
+            slot(std::integral_constant<int, 10>{}, nxt, ra, rb); slot(std::integral_constant<int, 11>{}, nxt, ra, rb);
+            slot(std::integral_constant<int, 12>{}, nxt, ra, rb); slot(std::integral_constant<int, 13>{}, nxt, ra, rb);
+            slot(std::integral_constant<int, 14>{}, nxt, ra, rb); slot(std::integral_constant<int, 15>{}, nxt, ra, rb);
+        }
         __syncthreads();
     };
     int t = 0;
