@@ -12,6 +12,7 @@
 // 8- (32x32x2) or 16-deep (16x16x4) sub-step, A and B permuted identically, so the products are exact fp32 fmas.
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 #include "conv_gather.h"
 #include "kernel_timer.h"
@@ -47,6 +48,12 @@ using Tile128x128k32 = Tile<128, 128, 64, 64, 32, 32>;
 using Tile64x64k32 = Tile<64, 64, 32, 32, 32, 32>;
 using Tile64x64k64 = Tile<64, 64, 32, 32, 32, 64>;       // 64-deep: 32 MFMAs per wavefront between barriers
 using Tile32x64k32 = Tile<32, 64, 32, 16, 16, 32>;       // short tiles for the 6x20 maps of layer4 (M = 2880): twice the workgroups
+
+// f(integral_constant<int, 0>{}), ..., f(integral_constant<int, N - 1>{}): a loop whose index is a compile-time constant in the body
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // destination pixel of GEMM row m: returns false for padding rows.
 __device__ __forceinline__ bool decode_row(const IgemmParams& p, int m, int& n, int& dy, int& dx) {
@@ -811,12 +818,144 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     // loads outstanding are exactly that tile's), issues tile t + 2 into the same registers, runs the MFMAs of tile t -- which
     // cover the LDS-write latency and the flight of the new loads -- and ends with the one barrier.
     f32x4 ra[T::AROWS], rb[T::BVECS];
+    // Steady-state step.  A wavefront issues in order and (with one accumulator tile) its MFMAs form one dependent chain, so the rest of
+    // the step -- LDS stores of tile t + 1, global loads of tile t + 2, the pointer advance -- is cut into pieces and one or two pieces
+    // are placed behind each MFMA group, where they issue while the MFMA pipe works, instead of in a block in front of the MFMAs.
+    constexpr int NKS = CKT / KSUB, NSLOT = NKS * 4, NPIECE = T::AROWS + T::BVECS + 4;
+    f32x4 fa[2][T::TM], fb[2][T::TN];
+    auto rdf = [&](auto bufc, int s, int ks) {
+        constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i) fa[s][i] = *reinterpret_cast<const f32x4*>(&As[buf][wm0 + i * MFR + frow][ks * KSUB + fk]);
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) fb[s][j] = *reinterpret_cast<const f32x4*>(&Bs[buf][wn0 + j * MFR + frow][ks * KSUB + fk]);
+    };
+    auto piece = [&](auto pc, auto nxt) {
+        constexpr int P = decltype(pc)::value, buf = decltype(nxt)::value;
+        if constexpr (P < T::AROWS) {                                   // A store (+ the reflected contributions of a border wavefront)
+            if constexpr (REFL) {
+                if (wave_border) ra[P] += (ex0[P] + ex1[P]) + ex2[P];
+            }
+            *reinterpret_cast<f32x4*>(&As[buf][r0 + T::RPP * P][c4 * 4]) = ra[P];
+        } else if constexpr (P < T::AROWS + T::BVECS) {                 // B store
+            constexpr int j = P - T::AROWS;
+            const int e = tid + 256 * j, nn = e / T::LPR, cb = e % T::LPR;
+            if (BFULL || nn < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nn][cb * 4]) = rb[j];
+        } else if constexpr (P == T::AROWS + T::BVECS) {                // A loads of the tile after next
+            if constexpr (UPM) {
+                const int cb4 = chunk * CKT * 4;
+                if (__builtin_amdgcn_readfirstlane(seg) == 0) {
+                    asm volatile("; x1 segment: merged taps (A)" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < T::AROWS; ++j) ra[j] = buf_load4s(rs1, oa[j], cb4);
+                } else {
+                    asm volatile("; x2 segment: nine taps (A)" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < T::AROWS; ++j) ra[j] = buf_load4s(rs2, oa[j], cb4);
+                }
+            } else {
+                const int cbase = chunk * CKT;
+                if (cbase < g.C1) {
+#pragma unroll
+                    for (int j = 0; j < T::AROWS; ++j) ra[j] = buf_load4s(rs1, oa[j], cbase * 4);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < T::AROWS; ++j) ra[j] = buf_load4s(rs2, ob[j], (cbase - g.C1) * 4);
+                }
+            }
+        } else if constexpr (P == T::AROWS + T::BVECS + 1) {            // REFL: the up to three reflected sources of a border wavefront
+            if constexpr (REFL) {
+                if (wave_border) {
+                    const int cbase = chunk * CKT;
+                    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                    for (int j = 0; j < T::AROWS; ++j) {
+                        const int r = r0 + T::RPP * j;
+                        const int n = s_rn[r], dy = s_ry[r], dx = s_rx[r];
+                        const int sy = dy + 1 - ky, sx = dx + 1 - kx;
+                        const int ey = (dy == 1 && ky == 0) ? 0 : ((dy == g.Hs - 2 && ky == 2) ? g.Hs - 1 : -1);
+                        const int ex = (dx == 1 && kx == 0) ? 0 : ((dx == g.Ws - 2 && kx == 2) ? g.Ws - 1 : -1);
+                        const bool syok = (unsigned)sy < (unsigned)g.Hs, sxok = (unsigned)sx < (unsigned)g.Ws;
+                        const int rowb = n * g.Hs, cb = c4 * 4;
+                        const unsigned a0 = (unsigned)((((rowb + ey) * g.Ws + sx) * g.C1 + cb) * 4);
+                        const unsigned a1 = (unsigned)((((rowb + sy) * g.Ws + ex) * g.C1 + cb) * 4);
+                        const unsigned a2 = (unsigned)((((rowb + ey) * g.Ws + ex) * g.C1 + cb) * 4);
+                        ex0[j] = buf_load4s(rs1, (n >= 0 && ey >= 0 && sxok) ? a0 : OOB, cbase * 4);
+                        ex1[j] = buf_load4s(rs1, (n >= 0 && ex >= 0 && syok) ? a1 : OOB, cbase * 4);
+                        ex2[j] = buf_load4s(rs1, (n >= 0 && ey >= 0 && ex >= 0) ? a2 : OOB, cbase * 4);
+                    }
+                }
+            }
+        } else if constexpr (P == T::AROWS + T::BVECS + 2) {            // B loads
+            if constexpr (UPM) {
+                const int cb4 = chunk * CKT * 4;
+                if (__builtin_amdgcn_readfirstlane(seg) == 0) {
+                    asm volatile("; x1 segment: merged taps (B)" ::: "memory");
+                    const int kb = (tap * g.C1) * 4 + cb4;
+#pragma unroll
+                    for (int j = 0; j < T::BVECS; ++j) rb[j] = buf_load4s(rsm, bcur[j], kb);
+                } else {
+                    asm volatile("; x2 segment: nine taps (B)" ::: "memory");
+                    const int kb = (tap * p.Kp + g.C1) * 4 + cb4;
+#pragma unroll
+                    for (int j = 0; j < T::BVECS; ++j) rb[j] = buf_load4s(rsw, bcur[j], kb);
+                }
+            } else {
+                const int kb = (tap * p.Kp + chunk * CKT) * 4;
+#pragma unroll
+                for (int j = 0; j < T::BVECS; ++j) rb[j] = buf_load4s(rsw, boff[j], kb);
+            }
+        } else {                                                        // advance the issue pointer
+            if constexpr (UPM) {
+                if (++chunk == (seg == 0 ? nch1 : nch2)) {
+                    chunk = 0;
+                    if (++tap == 4 && seg == 0) { seg = 1; tap = 0; }
+                    refresh();
+                }
+            } else {
+                if (++chunk == nchunks) {
+                    chunk = 0;
+                    ++ti;
+                    tap = __builtin_amdgcn_readfirstlane(s_tl[ti]);
+                    refresh();
+                }
+            }
+        }
+    };
     auto step = [&](auto cur, auto nxt) {
-        store(ra, rb, nxt);
-        issue(ra, rb);
-        __builtin_amdgcn_sched_barrier(0);      // keep the loads above the MFMAs
-        compute(cur);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TK != 0) {
+            // the merged-tap and reflection-adjoint kinds keep the block form: cut into pieces, the two-segment loads of the first made the
+            // compiler spill the offset arrays, and the second (border wavefronts carry 4x the loads in one register stage) measured slower
+            store(ra, rb, nxt);
+            issue(ra, rb);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            return;
+        }
+        rdf(cur, 0, 0);
+        static_for<NKS>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            if constexpr (ks + 1 < NKS) rdf(cur, (ks + 1) & 1, ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value, S = ks * 4 + q;
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::TN; ++j) {
+                        if constexpr (MFR == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks & 1][i][q], fb[ks & 1][j][q], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks & 1][i][q], fb[ks & 1][j][q], acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                // pieces go to the EARLIEST slots: the registers are stored first and re-loaded right after, so that the new loads have the
+                // rest of this step (and the first slots of the next) to land
+                constexpr int per = (NPIECE + NSLOT - 1) / NSLOT, lo = S * per < NPIECE ? S * per : NPIECE, hi = lo + per < NPIECE ? lo + per : NPIECE;
+                static_for<hi - lo>([&](auto kc) { piece(std::integral_constant<int, lo + decltype(kc)::value>{}, nxt); });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
         __syncthreads();
     };
     int t = 0;
