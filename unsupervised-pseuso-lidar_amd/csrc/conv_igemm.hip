@@ -923,17 +923,10 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
         }
     };
     auto step = [&](auto cur, auto nxt) {
-        if constexpr (TK != 0) {
-            // the merged-tap and reflection-adjoint kinds keep the block form: cut into pieces, the two-segment loads of the first made the
-            // compiler spill the offset arrays, and the second (border wavefronts carry 4x the loads in one register stage) measured slower
-            store(ra, rb, nxt);
-            issue(ra, rb);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(cur);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            return;
-        }
+        // The merged-tap and reflection-adjoint kinds keep their loads in one block (cut up, the two-segment loads of the first made the
+        // compiler spill the offset arrays; the second measured slower): for them the pieces are the stores, then issue() as a whole.
+        constexpr bool WHOLE_ISSUE = TK != 0;
+        constexpr int NP = WHOLE_ISSUE ? T::AROWS + T::BVECS + 1 : NPIECE;
         rdf(cur, 0, 0);
         static_for<NKS>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value;
@@ -951,8 +944,12 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 // pieces go to the EARLIEST slots: the registers are stored first and re-loaded right after, so that the new loads have the
                 // rest of this step (and the first slots of the next) to land
-                constexpr int per = (NPIECE + NSLOT - 1) / NSLOT, lo = S * per < NPIECE ? S * per : NPIECE, hi = lo + per < NPIECE ? lo + per : NPIECE;
-                static_for<hi - lo>([&](auto kc) { piece(std::integral_constant<int, lo + decltype(kc)::value>{}, nxt); });
+                constexpr int per = (NP + NSLOT - 1) / NSLOT, lo = S * per < NP ? S * per : NP, hi = lo + per < NP ? lo + per : NP;
+                static_for<hi - lo>([&](auto kc) {
+                    constexpr int P = lo + decltype(kc)::value;
+                    if constexpr (WHOLE_ISSUE && P == T::AROWS + T::BVECS) issue(ra, rb);
+                    else piece(std::integral_constant<int, P>{}, nxt);
+                });
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
