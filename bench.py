@@ -49,6 +49,18 @@ def measured_traffic(steps_in_profile=3):
     return conv / steps_in_profile, (warp[0] if warp and warp[0] > 0 else None)
 
 
+def workload_label(B, H, W, layers, ssim):
+    if (B, H, W, layers, ssim) == (12, 192, 640, 18, False):
+        return "BASELINE.json configs[1]"
+    if (H, W, layers, ssim) == (320, 1024, 50, True):
+        return "BASELINE.json configs[3]" + ("" if B == 12 else " at batch %d" % B)
+    if (B, H, W, layers, ssim) == (2, 64, 128, 18, False):
+        return "BASELINE.json configs[0] shape on the GPU"
+    if (B, H, W, layers, ssim) == (4, 192, 640, 18, False):
+        return "north_star's 4x3x192x640 batches (configs[1] at batch 4)"
+    return "variant of BASELINE.json configs[1]"
+
+
 def synthetic_samples(B, H, W, rank, step=0):
     from dataloaders import synthetic_batch
     return synthetic_batch(B, H, W, seed=1234 + 1000 * rank + step)
@@ -88,14 +100,16 @@ def make_step(depth, pose, opt, crit, samples, pair=True, graph=False):
         return tuple(loss)
 
     runner = fwd_bwd
+    adam_in_graph = False
     if graph:
         try:
-            from mcav.graph import GraphedForwardBackward
-            runner = GraphedForwardBackward(fwd_bwd, opt.arena(), [tgt, refs[0], refs[1], K])
+            from mcav.graph import GraphedStep
+            adam_in_graph = mdist.world() == 1            # one rank: the fused Adam is part of the graph (device-side step / lr scalars)
+            runner = GraphedStep(fwd_bwd, opt, [tgt, refs[0], refs[1], K], capture_adam=adam_in_graph, buffers=list(depth.buffers()))
         except Exception as e:       # a failed capture must not cost the measurement: same launches, issued eagerly
             print("bench.py: hipGraph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
             torch.cuda.synchronize()
-            runner = fwd_bwd
+            runner, adam_in_graph = fwd_bwd, False
     if graph:
         make_step.graphed = runner is not fwd_bwd
 
@@ -104,38 +118,46 @@ def make_step(depth, pose, opt, crit, samples, pair=True, graph=False):
         hook, N.GRADS_READY = N.GRADS_READY, (N.GRADS_READY if collective else None)
         loss = runner(tgt, refs[0], refs[1], K)
         N.GRADS_READY = hook
+        if adam_in_graph:
+            return loss
         opt.grad_scale = mdist.allreduce_gradients(opt.arena()) if collective else 1.0 / mdist.world()
         opt.step()
         return loss
     return step
 
 
-def cpu_baseline(B, H, W, steps=2):
-    """The CPU oracle's full step (stock PyTorch ops) on the host cores; bounded sample."""
+def cpu_baseline(H, W, depth_layers=18, ssim=False, batch=4, warm=1, steps=5):
+    """The CPU oracle's full step (stock PyTorch ops) on the host cores; bounded sample (SURVEY.md 8d asks for 3 + 10 steps at B = 4 and 12:
+    at ~4 s per B = 4 step and ~11.5 s per B = 12 step that is minutes of CPU work inside a bench run that must finish in minutes, so the
+    default is 1 warm-up + 5 timed steps at B = 4 (~25 s), median reported; images/s per core count is batch-size independent to ~10 %)."""
     from oracle import nets as onets
     from oracle.step import make_optimizer, synthetic_batch, train_step
     torch.manual_seed(0)
-    depth, pose = onets.DispResNet(), onets.PoseNet()
+    depth, pose = onets.DispResNet(depth_layers), onets.PoseNet()
     pose.init_weights()
     depth.train()
     pose.train()
     opt = make_optimizer(depth, pose, 1e-4)
-    s = synthetic_batch(B, H, W, seed=1234)
-    train_step(depth, pose, opt, s)                      # warm-up
-    t0 = time.perf_counter()
+    s = synthetic_batch(batch, H, W, seed=1234)
+    for _ in range(warm):
+        train_step(depth, pose, opt, s, ssim_weight=0.85 if ssim else 0.0)
+    ts = []
     for _ in range(steps):
-        train_step(depth, pose, opt, s)
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": round(B / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d full steps (after 1 warm-up) of the same batch=%d %dx%d ResNet-18+PoseNet fp32 workload, oracle/ in stock PyTorch "
-                      "CPU ops, %.2f s/step, os.cpu_count()=%d" % (steps, B, H, W, dt, os.cpu_count())}
+        t0 = time.perf_counter()
+        train_step(depth, pose, opt, s, ssim_weight=0.85 if ssim else 0.0)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    dt = ts[len(ts) // 2]
+    return {"value": round(batch / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "median of %d full steps (after %d warm-up) of the same %dx%d ResNet-%d+PoseNet fp32 workload at batch=%d, oracle/ in stock "
+                      "PyTorch CPU ops, %.2f s/step (min %.2f, max %.2f), os.cpu_count()=%d" % (steps, warm, H, W, depth_layers, batch, dt, ts[0], ts[-1], os.cpu_count())}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)      # SURVEY.md 8d: 20 warm-up + 100 timed steps, median and p10 / p90 reported
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
@@ -188,11 +210,16 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # per-step durations without a host sync in the loop
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()           # on the stream every stream of the step has been joined into
     fence()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -205,11 +232,17 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "%s: per-GPU batch=%d, %dx%d KITTI-shaped triplets, ResNet-%d depth encoder + 6-DoF PoseNet, "
                                   "fp32, one step = 2x depth fwd + pose fwd + warp/%s/smooth loss + backward + Adam%s" %
-                                  ("BASELINE.json configs[1]" if (B, H, W, args.depth_layers, args.ssim) == (12, 192, 640, 18, False)
-                                   else "variant of BASELINE.json configs[1]",
+                                  (workload_label(B, H, W, args.depth_layers, args.ssim),
                                    B, H, W, args.depth_layers, "SSIM+L1" if args.ssim else "L1", " + 1 RCCL all-reduce of the gradient arena" if world > 1 else ""),
                       "global_batch": B * world, "parallelism": "dp%d" % world},
-           "loss": [round(float(l.detach()), 6) for l in loss], "hipgraph": bool(getattr(make_step, "graphed", False))}
+           "loss": [round(float(l.detach()), 6) for l in loss], "hipgraph": bool(getattr(make_step, "graphed", False)),
+           "ms_per_step_median": round(pct(0.5), 4), "ms_per_step_p10": round(pct(0.1), 4), "ms_per_step_p90": round(pct(0.9), 4)}
+    if world > 1:
+        gs = mdist._SYNC.get(id(opt.arena()))
+        out["config"]["dp"] = {"rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                               "gradient_arena_bytes": int(opt.arena().numel) * 4,
+                               "allreduce_buckets_bytes": [int(b) for b in (gs.last_buckets if gs is not None else [int(opt.arena().numel) * 4])],
+                               "overlap_with_backward": bool(gs is not None and not getattr(make_step, "graphed", False))}
 
     if rank == 0 and not args.no_roofline:
         # instrumented step(s): every conv kernel dispatched with its own start/stop HIP events (csrc/kernel_timer.h), on one stream
@@ -266,7 +299,7 @@ def main():
                                     "ms": round(lms, 4), "main_kernel_ms": round(lmain, 4),
                                     "note": "achieved = 52 B/pixel over the three launches of the loss stage (per-dispatch HIP events); traffic = PMC bytes of the main kernel"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(B, H, W)
+        out["cpu_baseline"] = cpu_baseline(H, W, args.depth_layers, args.ssim)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -214,6 +214,11 @@ int mcav_copy_channels(const float* src, size_t n_pix, int Cs, int soff, float* 
 int mcav_resize_bilinear_fwd(const float* src, int B, int h, int w, float* dst, int H, int W, float scale_y, float scale_x, void* stream);
 int mcav_resize_bilinear_bwd(const float* ddst, int B, int h, int w, float* dsrc, int H, int W, float scale_y, float scale_x, int accumulate,
                              void* stream);
+/* `upsample` (reference models/depth/layers.py:55-58: F.interpolate(x, scale_factor=2, mode="nearest")) on `planes` = B*C contiguous
+ * [h, w] planes (NCHW) -> [2h, 2w], and its adjoint (each source pixel collects its 2x2 block).  Inside the depth decoder the upsample is
+ * fused into the following conv's gather (mcav_igemm_desc.up1); these are the standalone op of the reference's call surface. */
+int mcav_upsample_nearest2x(const float* src, size_t planes, int h, int w, float* dst, void* stream);
+int mcav_upsample_nearest2x_bwd(const float* grad_out, size_t planes, int h, int w, float* grad_in, void* stream);
 int mcav_affine(const float* x, float a, float b, size_t n, float* y, void* stream);      /* y = a x + b */
 int mcav_mul(const float* a, const float* b, size_t n, float* y, void* stream);          /* y = a * b */
 /* out[c] (+)= sum over pixels of x[p, c]  (bias gradient of ConvTranspose2d) */
@@ -224,6 +229,12 @@ int mcav_colsum(const float* x, size_t n_pix, int C, float* out, int accumulate,
  * step is the 1-based step count AFTER this update.  grad_scale multiplies the gradient first (1/world_size for DP). */
 int mcav_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
                    float eps, int step, float grad_scale, void* stream);
+
+/* The same update with its per-step scalars in DEVICE memory, so that the launch can be captured in a hipGraph and replayed (reference site:
+ * optimizer.step() at trainer.py:266 inside the captured step).  state8: 8 floats { step count BEFORE this update (incremented by the call),
+ * lr, grad_scale, and five words the call owns }.  The host sets step / lr / grad_scale; every call advances the count by one. */
+int mcav_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float beta1, float beta2, float eps,
+                       float* state8, void* stream);
 
 #ifdef __cplusplus
 }

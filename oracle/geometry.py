@@ -11,6 +11,8 @@ Restates, batch-generic and device-generic:
 
 The reference hard-codes ``.cuda()`` (transform.py:134) and ``repeat(4, ...)`` (transform.py:110);
 the arithmetic below is the same sequence of fp32 operations without those two restrictions.
+Every function follows the dtype of its floating-point inputs, so the same code evaluated on .double() inputs is the
+fp64 arbiter the GPU tests use to judge which of two fp32 evaluations (HIP, CPU) is closer to the exact result.
 """
 import torch
 import torch.nn.functional as F
@@ -85,7 +87,7 @@ def pixel_grid(B, H, W, dtype, device):
 def reconstruct(depth, K):
     """depth [B,H,W], K [B,3,3] (any float dtype) -> camera points [B,3,H,W]."""
     B, H, W = depth.shape
-    Kinv = K.inverse().float()
+    Kinv = K.inverse().to(depth.dtype)      # .float() in the reference (transform.py:92); the fp64 arbiter mode of the tests keeps fp64
     rays = Kinv.bmm(pixel_grid(B, H, W, depth.dtype, depth.device)).view(B, 3, H, W)
     return rays * depth.unsqueeze(1)
 
@@ -94,7 +96,7 @@ def project(X, K, Tcw):
     """X [B,3,H,W], K [B,3,3], Tcw [B,4,4] -> sampling grid [B,H,W,2] in [-1,1] (x, y)."""
     B, _, H, W = X.shape
     Xh = torch.cat([X.view(B, 3, -1), torch.ones(B, 1, H * W, dtype=X.dtype, device=X.device)], 1)
-    K4 = torch.eye(4, device=K.device).repeat(B, 1, 1)      # float32, as the reference's torch.eye(4)
+    K4 = torch.eye(4, dtype=X.dtype, device=K.device).repeat(B, 1, 1)      # float32 for float32 points, as the reference's torch.eye(4)
     K4[:, :3, :3] = K
     P = (K4 @ Tcw)[:, :3, :]
     cam = P @ Xh

@@ -388,6 +388,7 @@ if __name__ == "__main__":
     case_ssim()
     case_loss_ssim()
     case_smooth()
+    case_preprocess()
     keys = {"PoseNet": case_posenet(), "DepthDecoder": case_decoder(), "DispResNet": case_dispresnet(),
             "DispNetS": case_dispnets(), "PoseFc": case_posefc()}
     with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:

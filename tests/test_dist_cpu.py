@@ -105,3 +105,32 @@ def test_two_rank_bucketed_overlap_equals_one_allreduce():
         want = sum(torch.randn(numel, generator=torch.Generator().manual_seed(1000 * step + r)) for r in range(2))
         assert r0[step] == r1[step]
         assert torch.equal(torch.tensor(r0[step]), want)           # every element summed exactly once
+
+
+def test_gradsync_buckets_on_the_real_networks():
+    """The ranges the depth net's backward announces (decoder first, then encoder layer4: models/depth/resnet_dispnet.py _DispResNetPairFn,
+    mcav/depthnet.py encoder_backward) must be contiguous runs of the REAL DispResNet + PoseNet arena, disjoint, and cover most of its
+    bytes -- otherwise GradSync.ready() silently leaves everything to finish() and nothing overlaps with backward."""
+    from mcav import dist as mdist
+    from mcav.arena import Arena
+    from models.depth.resnet_dispnet import DispResNet
+    from models.pose.pose_net import PoseNet
+    for layers, min_cover in ((18, 0.70), (50, 0.55)):
+        depth, pose = DispResNet(layers), PoseNet()
+        params = list(depth.parameters()) + list(pose.parameters())
+        a = Arena(params)
+        gs = mdist.GradSync(a)
+        r_dec = gs.span(list(depth.decoder.parameters()))
+        r_l4 = gs.span(list(depth.encoder.encoder.layer4.parameters()))
+        assert r_dec is not None and r_l4 is not None, "announced groups are not contiguous arena ranges"
+        assert r_dec[1] <= r_l4[0] or r_l4[1] <= r_dec[0], "announced ranges overlap"
+        for lo, hi in (r_dec, r_l4):
+            assert 0 <= lo < hi <= a.numel
+        # each range holds exactly its group's parameters (16-byte slot padding included, nothing else)
+        n_dec = sum((p.numel() + 3) // 4 * 4 for p in depth.decoder.parameters())
+        n_l4 = sum((p.numel() + 3) // 4 * 4 for p in depth.encoder.encoder.layer4.parameters())
+        assert r_dec[1] - r_dec[0] == n_dec and r_l4[1] - r_l4[0] == n_l4
+        cover = (n_dec + n_l4) / a.numel
+        assert cover >= min_cover, (layers, cover)
+        # a group that is NOT one run (layer4 + pose net: the decoder lies between them) is refused rather than mis-reduced
+        assert gs.span(list(depth.encoder.encoder.layer4.parameters()) + list(pose.parameters())) is None

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 import torch
 
+from arbiter import Verdicts
 from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
@@ -69,6 +70,26 @@ def test_losses_ka1(golden):
     # coordinate, where the bilinear derivative jumps; the pose gradient is a random-walk sum over pixels, so a couple
     # of such pixels move it at the 1e-3..1e-2 level (measured 4e-3 on MI355X vs the CPU reference).
     assert rel_err(p.grad, g["g_poses"]) < 2e-2
+    # ... and the arbiter under that bound: the same inputs through the oracle in float64 and in float32.  The HIP gradients must be as
+    # close to the float64 ones as stock PyTorch fp32 is (a real indexing error would not be).
+    v = Verdicts()
+    for name, hip_g, grads in (("KA1", (dt.grad, dr.grad, p.grad), oracle_loss_grads(tgt, refs, disp_t, disp_r, poses, K)),):
+        g32, g64 = grads
+        for n, a, b, c in zip(("d disp_t", "d disp_r", "d poses"), hip_g, g32, g64):
+            v.add(name + " " + n, a, b, c)
+    v.check("test_losses_ka1")
+
+
+def oracle_loss_grads(tgt, refs, disp_t, disp_r, poses, K, ssim_weight=0.0):
+    """-> (fp32 grads, fp64 grads) of sum(Losses.forward) w.r.t. (disp_t, disp_r, poses) from the CPU oracle."""
+    from oracle import losses as ol
+    out = []
+    for dt_ in (torch.float32, torch.float64):
+        a, b, c = (t.detach().to(dt_).clone().requires_grad_() for t in (disp_t, disp_r, poses))
+        loss = ol.losses_forward(tgt.to(dt_), [r.to(dt_) for r in refs], [[a], [b]], c, K, ssim_weight)
+        sum(loss).backward()
+        out.append((a.grad, b.grad, c.grad))
+    return out
 
 
 @pytest.mark.parametrize("up", [None, (1.0, 0.0), (0.7, 1.3)])
@@ -239,10 +260,18 @@ def test_losses_vs_oracle_at_size(B, H, W):
     grad_close(x.grad, a.grad, l2=3e-2)
     grad_close(y.grad, b.grad, l2=3e-2)
     assert rel_err(z.grad, c.grad) < 5e-3      # a sum over 4.4 M sign terms: measured 1e-3..2.6e-3 depending on the host's CPU kernels
+    # the arbiter under those bounds: both fp32 evaluations against the float64 one
+    g32, g64 = oracle_loss_grads(s["tgt"], s["ref_imgs"], disp_t, disp_r, poses, s["intrinsics"])
+    v = Verdicts()
+    for n, hg, cg, rg in zip(("d disp_t", "d disp_r", "d poses"), (x.grad, y.grad, z.grad), g32, g64):
+        v.add("%dx%dx%d %s" % (B, H, W, n), hg, cg, rg)
+    v.check("test_losses_vs_oracle_at_size")
 
 
-def test_multiscale_losses_vs_oracle():
-    """Four disparity scales (DispNetS): every coarser depth is resized bilinearly before warping (losses.py:212-216)."""
+@pytest.mark.parametrize("ssim", [False, True])
+def test_multiscale_losses_vs_oracle(ssim):
+    """Four disparity scales (DispNetS): every coarser depth is resized bilinearly before warping (losses.py:212-216); with ssim the
+    photometric term of every scale is the 0.85 SSIM + 0.15 L1 mix (composed per scale as the reference does, losses.py:209-221)."""
     from losses import Losses
     from oracle import losses as ol
     from oracle.step import synthetic_batch
@@ -256,12 +285,12 @@ def test_multiscale_losses_vs_oracle():
     a = [t.clone().requires_grad_() for t in dt]
     b = [t.clone().requires_grad_() for t in dr]
     c = poses.clone().requires_grad_()
-    want = ol.losses_forward(s["tgt"], s["ref_imgs"], [a, b], c, s["intrinsics"])
+    want = ol.losses_forward(s["tgt"], s["ref_imgs"], [a, b], c, s["intrinsics"], 0.85 if ssim else 0.0)
     sum(want).backward()
     x = [t.to(DEV).requires_grad_() for t in dt]
     y = [t.to(DEV).requires_grad_() for t in dr]
     z = poses.to(DEV).requires_grad_()
-    got = Losses().forward(s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], [x, y], z, s["intrinsics"].to(DEV), None)
+    got = Losses(ssim=ssim).forward(s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], [x, y], z, s["intrinsics"].to(DEV), None)
     assert abs(float(got[0]) - float(want[0])) < 2e-5 * abs(float(want[0]))
     assert abs(float(got[1]) - float(want[1])) < 2e-5 * abs(float(want[1]))
     sum(got).backward()

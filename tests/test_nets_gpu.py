@@ -122,6 +122,19 @@ def test_dispresnet50_vs_oracle():
             continue
         e = float((p.grad.cpu() - rp[n].grad).norm() / rp[n].grad.norm().clamp_min(1e-20))
         assert e < 5e-2, (n, e)      # 50+ BatchNorm/ReLU layers deep: mask flips accumulate towards the stem (measured 2.8e-2 at conv1)
+    # the arbiter under that bound: the same network in float64; HIP must be as close to it as the CPU fp32 oracle is
+    from arbiter import Verdicts, double_copy
+    ref64 = double_copy(ref)
+    ref64.zero_grad()
+    out64 = ref64(x.double())[0]
+    (out64 * coef.double()).sum().backward()
+    r64 = dict(ref64.named_parameters())
+    v = Verdicts()
+    v.add("disparity", got, want, out64)
+    for n, p in hip.named_parameters():
+        if rp[n].grad is not None:
+            v.add(n, p.grad, rp[n].grad, r64[n].grad)
+    v.check("test_dispresnet50_vs_oracle")
     # the stacked two-pass form gives the same disparities
     hip2 = reinit_by_name(DispResNet50(), 77).to(DEV).train()
     a, b = hip2.forward_pair(x.to(DEV), x.flip(0).contiguous().to(DEV))

@@ -12,12 +12,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def build_pair(seed_d=141, seed_p=121):
+def build_pair(seed_d=141, seed_p=121, layers=18):
     from models.depth.resnet_dispnet import DispResNet
     from models.pose.pose_net import PoseNet
     from oracle import nets as on
-    hip_d, hip_p = reinit_by_name(DispResNet(), seed_d), reinit_by_name(PoseNet(), seed_p)
-    ref_d, ref_p = on.DispResNet(), on.PoseNet()
+    hip_d, hip_p = reinit_by_name(DispResNet(layers), seed_d), reinit_by_name(PoseNet(), seed_p)
+    ref_d, ref_p = on.DispResNet(layers), on.PoseNet()
     ref_d.load_state_dict(hip_d.state_dict())        # same names and shapes: the state_dict is interchangeable
     ref_p.load_state_dict(hip_p.state_dict())
     with torch.no_grad():                            # small pose outputs, as a trained/initialised PoseNet gives
@@ -27,14 +27,18 @@ def build_pair(seed_d=141, seed_p=121):
     return hip_d.to(DEV).train(), hip_p.to(DEV).train(), ref_d.train(), ref_p.train()
 
 
-@pytest.mark.parametrize("B,H,W,pair,ssim", [(2, 64, 128, False, False), (3, 96, 160, False, False), (2, 64, 128, True, False),
-                                              (3, 96, 160, True, False), (2, 64, 128, True, True)])
-def test_train_step_vs_oracle(B, H, W, pair, ssim):
+# the last two cases are BASELINE.json configs[3]'s combination (ResNet-50 encoder + the fused warp + SSIM loss) as ONE step
+@pytest.mark.parametrize("B,H,W,pair,ssim,layers", [(2, 64, 128, False, False, 18), (3, 96, 160, False, False, 18), (2, 64, 128, True, False, 18),
+                                                     (3, 96, 160, True, False, 18), (2, 64, 128, True, True, 18),
+                                                     (2, 64, 128, True, True, 50), (2, 96, 160, True, True, 50)])
+def test_train_step_vs_oracle(B, H, W, pair, ssim, layers):
     from losses import Losses
     from mcav.optim import FusedAdam
     from oracle.step import make_optimizer, synthetic_batch, train_step
-    hip_d, hip_p, ref_d, ref_p = build_pair()
+    hip_d, hip_p, ref_d, ref_p = build_pair(layers=layers)
     s = synthetic_batch(B, H, W, seed=5)
+    from arbiter import Verdicts, double_copy, to_double
+    d64, p64 = double_copy(ref_d), double_copy(ref_p)          # the float64 arbiter: same weights, same code, before the update
     ropt = make_optimizer(ref_d, ref_p, 1e-4)
     (rdisps, rposes), rloss = train_step(ref_d, ref_p, ropt, s, ssim_weight=0.85 if ssim else 0.0)
 
@@ -63,6 +67,20 @@ def test_train_step_vs_oracle(B, H, W, pair, ssim):
         e = float((p.grad.cpu() - q.grad).norm() / q.grad.norm().clamp_min(1e-20))
         worst = max(worst, e)
         assert e < 2e-2, (n, e)
+    # the arbiter under that bound: the step in float64 (same weights); per parameter HIP must be as close to it as the CPU fp32 oracle
+    s64 = to_double(s)
+    from oracle.step import process_batch
+    (disps64, poses64), loss64 = process_batch(d64, p64, s64, ssim_weight=0.85 if ssim else 0.0)
+    sum(loss64).backward()
+    v = Verdicts()
+    v.add("disp(tgt)", disps[0][0], rdisps[0][0], disps64[0][0])
+    v.add("poses", poses, rposes, poses64)
+    for (n, p), (_, q), (_, r) in zip(list(hip_d.named_parameters()) + list(hip_p.named_parameters()),
+                                      list(ref_d.named_parameters()) + list(ref_p.named_parameters()),
+                                      list(d64.named_parameters()) + list(p64.named_parameters())):
+        if q.grad is not None:
+            v.add(n, p.grad, q.grad, r.grad)
+    v.check("test_train_step_vs_oracle[%d-%d-%d-%s-%s-R%d]" % (B, H, W, pair, ssim, layers))
     # optimiser parity after the update
     opt.step()
     torch.cuda.synchronize()
@@ -101,6 +119,120 @@ def test_mixed_resolution_steps_share_no_state():
     la2, ga2 = run(2, 64, 128, 5)
     assert la == la2 and lb != la and lc != la
     assert all(torch.equal(x, y) for x, y in zip(ga, ga2))
+
+
+def test_mixed_resolution_full_size_alternation():
+    """BASELINE.json configs[4] at its real shapes: batch-12 steps alternating 192x640 and 256x832 through one process (one resolution per
+    step).  The step at 192x640 gives bit-identical losses and gradients before and after a 256x832 step from the same weights: nothing
+    cached for one resolution (offset tables, workspaces, packed filters, stream state) leaks into the other."""
+    from losses import Losses
+    from mcav.optim import FusedAdam
+    from mcav.streams import Branch
+    from oracle.step import synthetic_batch
+    hip_d, hip_p, _, _ = build_pair()
+    opt = FusedAdam(list(hip_d.parameters()) + list(hip_p.parameters()), 1e-4)
+    state = {k: v.clone() for k, v in hip_d.state_dict().items()}
+    branch = Branch()
+
+    def run(H, W, seed):
+        s = synthetic_batch(12, H, W, seed=seed)
+        tgt, refs, K = s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], s["intrinsics"].to(DEV)
+        hip_d.load_state_dict(state)
+        opt.zero_grad()
+        poses = branch.fork(hip_p, tgt, refs)
+        disps = list(hip_d.forward_pair(tgt, refs[0]))
+        poses = branch.join(poses)
+        loss = Losses().forward(tgt, refs, disps, poses, K, None)
+        sum(loss).backward()
+        torch.cuda.synchronize()
+        return [float(l.detach()) for l in loss], opt.arena().gflat.clone()
+
+    la, ga = run(192, 640, 21)
+    lb, gb = run(256, 832, 22)
+    la2, ga2 = run(192, 640, 21)
+    lb2, gb2 = run(256, 832, 22)
+    assert la == la2 and torch.equal(ga, ga2)
+    assert lb == lb2 and torch.equal(gb, gb2)
+    assert la != lb and torch.isfinite(gb).all() and float(gb.abs().max()) > 0
+
+
+def test_config3_full_size_r50_ssim_properties():
+    """BASELINE.json configs[3] at full size (batch 12, 320x1024, ResNet-50 encoder, fused warp + SSIM loss), properties that need no oracle:
+    the whole step is bit-reproducible; the stacked depth passes equal two separate passes (loss to 1e-5, gradients to 1e-3 L2);
+    eval-mode depth maps of the two forms agree within the north_star's 1e-3."""
+    from losses import Losses
+    from mcav.optim import FusedAdam
+    from mcav.streams import Branch
+    from oracle.step import synthetic_batch
+    hip_d, hip_p, _, _ = build_pair(layers=50)
+    s = synthetic_batch(12, 320, 1024, seed=19)
+    tgt, refs, K = s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], s["intrinsics"].to(DEV)
+    opt = FusedAdam(list(hip_d.parameters()) + list(hip_p.parameters()), 1e-4)
+    state = {k: v.clone() for k, v in hip_d.state_dict().items()}
+    branch = Branch()
+    crit = Losses(ssim=True)
+
+    def step(pair=True):
+        hip_d.load_state_dict(state)
+        opt.zero_grad()
+        poses = branch.fork(hip_p, tgt, refs)
+        disps = list(hip_d.forward_pair(tgt, refs[0])) if pair else [hip_d(tgt), hip_d(refs[0])]
+        poses = branch.join(poses)
+        loss = crit.forward(tgt, refs, disps, poses, K, None)
+        sum(loss).backward()
+        torch.cuda.synchronize()
+        return [float(l.detach()) for l in loss], opt.arena().gflat.clone()
+
+    l1, g1 = step()
+    l2, g2 = step()
+    assert l1 == l2 and torch.equal(g1, g2)
+    assert float(g1.abs().max()) > 0 and torch.isfinite(g1).all()
+    l3, g3 = step(pair=False)
+    for a, b in zip(l1, l3):
+        assert abs(a - b) <= 1e-5 * abs(b)
+    assert float((g1 - g3).norm() / g3.norm()) < 1e-3
+    del g1, g2, g3
+    hip_d.eval()
+    with torch.no_grad():
+        pa, _ = hip_d.forward_pair(tgt, refs[0])
+        sa = hip_d(tgt)
+    ds, dn = 1 / (10 * pa[0] + 0.01), 1 / (10 * sa[0] + 0.01)
+    assert float(((ds - dn).abs() / dn).max()) < 1e-3 and float(((ds - dn).abs() / dn).mean()) < 1e-5
+
+
+def test_trainer_resume_equals_uninterrupted(tmp_path, monkeypatch):
+    """Reference trainer.py:143-152: a resumed run restores the networks AND the optimiser (Adam moments, step count).  Two steps, checkpoint,
+    third step == construct a new Trainer from the checkpoint (from_scratch: False), third step: parameters and moments bit for bit."""
+    import os
+    import yaml
+    from conftest import PKG
+    from oracle.step import synthetic_batch
+    from trainer import Trainer
+    monkeypatch.chdir(tmp_path)
+    cfg = yaml.full_load(open(os.path.join(PKG, "configs", "basic_config.yaml")))
+    cfg["datasets"]["augmentation"].update(image_width=128, image_height=64)
+    cfg["datasets"]["synthetic_length"] = 10
+    cfg["action"].update(batch_size=2, verbose=False, save_checkpoints=True, from_scratch=True)
+    batches = [synthetic_batch(2, 64, 128, seed=50 + i) for i in range(3)]
+    a = Trainer(cfg)
+    a.set_train()
+    a.train_step(batches[0])
+    a.train_step(batches[1])
+    a.save_chkpnt()
+    a.train_step(batches[2])
+    torch.cuda.synchronize()
+    cfg["action"]["from_scratch"] = False
+    b = Trainer(cfg)
+    b.set_train()
+    assert b.model_optimizer._step == 2
+    b.train_step(batches[2])
+    torch.cuda.synchronize()
+    oa, ob = a.model_optimizer, b.model_optimizer
+    assert torch.equal(oa.arena().flat, ob.arena().flat)
+    assert torch.equal(oa._m, ob._m) and torch.equal(oa._v, ob._v) and oa._step == ob._step == 3
+    assert [float(x) for x in a.loss] == [float(x) for x in b.loss]
+    for (n, x), (_, y) in zip(a.depth_model.state_dict().items(), b.depth_model.state_dict().items()):
+        assert torch.equal(x, y), n          # BatchNorm running statistics and counters included
 
 
 def test_second_step_uses_updated_weights():

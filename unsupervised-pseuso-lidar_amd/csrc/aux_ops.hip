@@ -159,6 +159,38 @@ __global__ __launch_bounds__(256) void upsample_adj_fold_kernel(const float* __r
     }
 }
 
+
+// nearest-neighbour x2 upsampling of NCHW planes (reference models/depth/layers.py:55-58 `upsample`) and its adjoint (2x2 sum)
+__global__ __launch_bounds__(256) void upsample_nearest2x_kernel(const float* __restrict__ src, size_t planes, int h, int w, float* __restrict__ dst) {
+    const int W = 2 * w, H = 2 * h;
+    const size_t total = planes * (size_t)H * (W / 2);          // one thread writes the two output pixels of a source pixel's row
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % w);
+        const size_t r = i / w;
+        const int oy = (int)(r % H);
+        const size_t pl = r / H;
+        const float v = src[(pl * h + (oy >> 1)) * w + x];
+        typedef float v2 __attribute__((ext_vector_type(2)));
+        const v2 o = {v, v};
+        reinterpret_cast<v2*>(dst)[(pl * H + oy) * w + x] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample_nearest2x_bwd_kernel(const float* __restrict__ g, size_t planes, int h, int w, float* __restrict__ out) {
+    const int W = 2 * w;
+    const size_t total = planes * (size_t)h * w;
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % w);
+        const size_t r = i / w;
+        const int y = (int)(r % h);
+        const size_t pl = r / h;
+        const v2 a = reinterpret_cast<const v2*>(g)[((pl * 2 * h + 2 * y) * W + 2 * x) / 2];
+        const v2 b = reinterpret_cast<const v2*>(g)[((pl * 2 * h + 2 * y + 1) * W + 2 * x) / 2];
+        out[i] = (a.x + a.y) + (b.x + b.y);
+    }
+}
+
 }  // namespace mcav
 
 using namespace mcav;
@@ -220,5 +252,17 @@ MCAV_EXPORT int mcav_upsample_adj_fold(const float* tmp, int B, int Hl, int Wl, 
     const size_t n4 = (size_t)B * Hl * Wl * (C / 4);
     const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
     upsample_adj_fold_kernel<<<blocks, 256, 0, as_stream(stream)>>>(tmp, B, Hl, Wl, C / 4, dact_aux, dact, addend, out);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_upsample_nearest2x(const float* src, size_t planes, int h, int w, float* dst, void* stream) {
+    if (!src || !dst || planes == 0 || h <= 0 || w <= 0) return MCAV_E_INVALID;
+    upsample_nearest2x_kernel<<<aux_grid(planes * 2 * h * w, 8192), 256, 0, as_stream(stream)>>>(src, planes, h, w, dst);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_upsample_nearest2x_bwd(const float* grad_out, size_t planes, int h, int w, float* grad_in, void* stream) {
+    if (!grad_out || !grad_in || planes == 0 || h <= 0 || w <= 0) return MCAV_E_INVALID;
+    upsample_nearest2x_bwd_kernel<<<aux_grid(planes * h * w, 8192), 256, 0, as_stream(stream)>>>(grad_out, planes, h, w, grad_in);
     return launch_status();
 }

@@ -375,6 +375,30 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     }
 }
 
+// Capturable form (hipGraph): the step count, learning rate and gradient scale live in a DEVICE record, so the same two launches are valid
+// for every replay.  state = { step (as float, exact to 2^24), lr, grad_scale, bias_correction1, sqrt(bias_correction2), 0, 0, 0 }.
+__global__ void adam_prepare_kernel(float* st, float b1, float b2) {
+    const float step = st[0] + 1.f;
+    st[0] = step;
+    st[3] = (float)(1.0 - pow((double)b1, (double)step));
+    st[4] = (float)sqrt(1.0 - pow((double)b2, (double)step));
+}
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g, float* m, float* v, size_t n, float b1, float b2, float eps,
+                                                       const float* __restrict__ st) {
+    const float lr = st[1], gscale = st[2], bc1 = st[3], bc2_sqrt = st[4];
+    const float step = lr / bc1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gr = g[i] * gscale;
+        const float mi = m[i] + (gr - m[i]) * (1.f - b1);
+        const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step * (mi / denom);
+    }
+}
+
 }  // namespace mcav
 
 using namespace mcav;
@@ -540,6 +564,15 @@ MCAV_EXPORT int mcav_adam_step(float* param, const float* grad, float* exp_avg, 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     adam_kernel<<<grid_for(n, 256, 8192), 256, 0, as_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1,
                                                                        (float)sqrt(bc2), grad_scale);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float beta1, float beta2, float eps,
+                                   float* state8, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !state8) return MCAV_E_INVALID;
+    if (n == 0) return MCAV_OK;
+    adam_prepare_kernel<<<1, 1, 0, as_stream(stream)>>>(state8, beta1, beta2);
+    adam_dev_kernel<<<grid_for(n, 256, 8192), 256, 0, as_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, state8);
     return launch_status();
 }
 

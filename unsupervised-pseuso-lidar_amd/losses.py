@@ -87,11 +87,7 @@ class Losses:
         self.ssim = bool(ssim)
 
     def _flags(self, n_scales):
-        if not self.ssim:
-            return 0
-        if n_scales != 1:
-            raise L.MCAVError("Losses(ssim=True): the SSIM photometric mix is implemented for single-scale disparity lists only")
-        return L.WL_SSIM
+        return L.WL_SSIM if self.ssim else 0
 
     def forward(self, tgt_img, ref_imgs, disparity, poses, intrinsics, gt=None):
         """-> [loss_mam, loss_smooth].  disparity = [disps(tgt), disps(ref0)], each a list over scales."""
@@ -100,7 +96,7 @@ class Losses:
         ssim_flag = self._flags(max(n, len(disp_r)))
         if n != 1 or len(disp_r) != 1:
             from mcav.multiscale import multiscale_losses
-            return multiscale_losses(tgt_img, ref_imgs, disparity, poses, intrinsics)
+            return multiscale_losses(tgt_img, ref_imgs, disparity, poses, intrinsics, ssim=self.ssim)
         tw = (0.25, 0.25, 0.5)     # mean of the two tgt-view L1 terms and the third term, averaged (losses.py:227-240)
         l0, l1 = _WarpLossFn.apply(disp_t[0].contiguous(), disp_r[0].contiguous(), poses.contiguous(), tgt_img.contiguous(),
                                    ref_imgs[0].contiguous(), ref_imgs[1].contiguous(), intrinsics.contiguous(), ssim_flag, tw)
@@ -113,7 +109,7 @@ class Losses:
         ssim_flag = self._flags(len(depths[0]))
         if len(depths[0]) != 1:
             from mcav.multiscale import multiscale_losses
-            return multiscale_losses(tgt, refs, depths, poses, intrinsics, inputs_are_depth=True)[0]
+            return multiscale_losses(tgt, refs, depths, poses, intrinsics, inputs_are_depth=True, ssim=self.ssim)[0]
         tw = (0.25, 0.25, 0.5)
         l0, _ = _WarpLossFn.apply(depths[0][0].contiguous(), depths[1][0].contiguous(), poses.contiguous(), tgt.contiguous(),
                                   refs[0].contiguous(), refs[1].contiguous(), intrinsics.contiguous(),

@@ -56,6 +56,8 @@ class GradSync:
         self.arena = arena
         self.works = []
         self.done = []          # [lo, hi) ranges already handed to a collective this step
+        self.sizes = []         # bytes of each collective issued this step, in issue order
+        self.last_buckets = []  # ... of the last finished step (bench.py reports it)
 
     def span(self, params):
         a = self.arena
@@ -83,6 +85,7 @@ class GradSync:
         else:
             self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
         self.done.append(r)
+        self.sizes.append(4 * (r[1] - r[0]))
 
     def finish(self):
         """Call after backward() has returned (all streams joined).  Reduces the remaining ranges, then waits for all."""
@@ -91,10 +94,12 @@ class GradSync:
             for lo, hi in sorted(self.done) + [(self.arena.numel, self.arena.numel)]:
                 if lo > pos:
                     self.works.append(dist.all_reduce(self.arena.gflat[pos:lo], op=dist.ReduceOp.SUM, async_op=True))
+                    self.sizes.append(4 * (lo - pos))
                 pos = max(pos, hi)
             for w in self.works:
                 w.wait()
-        self.works, self.done = [], []
+            self.last_buckets = self.sizes
+        self.works, self.done, self.sizes = [], [], []
 
 
 _SYNC = {}

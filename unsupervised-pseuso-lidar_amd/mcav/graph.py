@@ -1,39 +1,91 @@
-"""hipGraph capture of the forward + backward part of the training step.
+"""hipGraph capture of the training step.
 
-One step issues ~450 kernel launches; replayed as one hipGraph they cost one host call.  Captured: zero_grad, both depth
-passes, the pose net, the fused loss (forward and its gradients) and the whole backward, including the weight re-packing
-kernels (the packed copies are invalidated right before capture so their launches are part of the graph and therefore
-re-run on every replay, after each optimiser update).  NOT captured: the gradient all-reduce and the Adam launch (host
-scalars: step count, learning rate), which run eagerly after the replay.
-Inputs live in static buffers; a replay is only valid for the batch shape it was captured with (one graph per shape).
+One step issues a few hundred kernel launches; replayed as one hipGraph they cost one host call, which is what the small, host-issue-bound
+configurations need (BASELINE.json configs[0]-sized batches; configs[4] asks for one captured graph per resolution).  Captured: zero_grad,
+the weight re-packing kernels (the packed copies are invalidated right before capture so that their launches are part of the graph and
+re-run on every replay), both depth passes, the pose net, the fused loss (forward and its gradients), the whole backward and -- on one
+rank -- the fused Adam update (reference trainer.py:261-266 as ONE graph: its step count, learning rate and gradient scale are read from a
+device record, mcav_adam_step_dev).  With more than one rank the gradient all-reduce and Adam stay outside the graph and run eagerly after
+the replay; the bucketed overlap of mcav/dist.py is a host-side hook and is OFF under replay (GradSync.finish() then reduces the whole
+arena in one collective), and it is disabled during warm-up and capture so that no collective is issued from inside them.
+Inputs live in static buffers; a replay is only valid for the batch shape it was captured with: StepGraphs keeps one graph per shape.
 """
 import torch
 
 
-class GraphedForwardBackward:
-    def __init__(self, fwd_bwd, arena, example_inputs, warmup=3):
-        """fwd_bwd(*inputs) -> tuple of tensors (e.g. the two losses); must zero the gradients itself."""
+class GraphedStep:
+    def __init__(self, fwd_bwd, opt, example_inputs, capture_adam=True, warmup=2, buffers=()):
+        """fwd_bwd(*inputs) -> tuple of tensors (e.g. the two losses); must zero the gradients itself.  opt: FusedAdam.
+        Warm-up and capture really run the step: everything they change (parameters, moments, step count, `buffers` such as the BatchNorm
+        running statistics) is put back afterwards, so constructing the graph leaves the training state untouched."""
+        from . import nn as N
         from . import streams
-        streams.SERIAL = True                      # single-stream issue from here on (see streams.py)
-        self.arena = arena
+        self.opt, self.arena = opt, opt.arena()
+        self.capture_adam = bool(capture_adam)
         self.static_in = [x.clone() for x in example_inputs]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                arena.bump()
+        arena = self.arena
+        keep = [arena.flat.clone(), opt._m.clone(), opt._v.clone()] + [b.clone() for b in buffers]
+        step0 = opt._step
+        hook, N.GRADS_READY = N.GRADS_READY, None          # no collectives from inside warm-up / capture (see the module docstring)
+        serial0, streams.SERIAL = streams.SERIAL, True     # this ROCm replays a captured graph on one queue: capture it on one stream
+        try:
+            def whole():
                 out = fwd_bwd(*self.static_in)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        arena.bump()                              # every packed weight copy is stale -> its pack kernel is captured
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            out = fwd_bwd(*self.static_in)
-        self.static_out = tuple(o.detach() for o in out)
+                if self.capture_adam:
+                    opt.step_capturable()
+                return out
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    arena.bump()
+                    whole()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            arena.bump()                                  # every packed weight copy is stale -> its pack kernel is captured
+            opt.device_state()                            # host -> device scalars are up to date BEFORE capture (no copy inside it)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                out = whole()
+            self.static_out = tuple(o.detach() for o in out)
+        finally:
+            N.GRADS_READY = hook
+            streams.SERIAL = serial0
+        with torch.no_grad():                              # undo what warm-up and capture did to the training state
+            arena.flat.copy_(keep[0]); opt._m.copy_(keep[1]); opt._v.copy_(keep[2])
+            for b, k in zip(buffers, keep[3:]):
+                b.copy_(k)
+        opt._step = step0
+        opt._dev_mirror = None
+        arena.bump()
 
     def __call__(self, *inputs):
         for dst, src in zip(self.static_in, inputs):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        if self.capture_adam:
+            self.opt.device_state()                       # lr / grad_scale / step count as the host has them now
         self.graph.replay()
+        if self.capture_adam:
+            self.opt.note_replayed()
+        else:
+            self.arena.bump()                             # (the eager Adam that follows bumps again; harmless)
         return self.static_out
+
+
+class StepGraphs:
+    """One captured step per input shape (BASELINE.json configs[4]: batches of two resolutions alternate through one process)."""
+
+    def __init__(self, fwd_bwd, opt, capture_adam=True, buffers=()):
+        self.fwd_bwd, self.opt, self.capture_adam, self.buffers = fwd_bwd, opt, capture_adam, tuple(buffers)
+        self.graphs = {}
+
+    def __call__(self, *inputs):
+        key = tuple(tuple(x.shape) for x in inputs)
+        g = self.graphs.get(key)
+        if g is None:
+            g = self.graphs[key] = GraphedStep(self.fwd_bwd, self.opt, inputs, self.capture_adam, buffers=self.buffers)
+        return g(*inputs)
+
+
+GraphedForwardBackward = GraphedStep          # round-1 name

@@ -75,9 +75,10 @@ class _ResizeFn(torch.autograd.Function):
         return out, None, None
 
 
-def multiscale_losses(tgt, refs, disparity, poses, K, inputs_are_depth=False):
+def multiscale_losses(tgt, refs, disparity, poses, K, inputs_are_depth=False, ssim=False):
     """Losses.forward for depth nets that return several scales (DispNetS).  Per scale: depth (from disparity), bilinear resize
-    to the image size, the fused 3-warp L1 kernel on the resized depths; smoothness on the native-resolution depths of tgt."""
+    to the image size, the fused 3-warp kernel (L1, or the 0.85 SSIM + 0.15 L1 mix when ssim: the reference composes its photometric
+    term per scale, losses.py:209-221) on the resized depths; smoothness on the native-resolution depths of tgt."""
     import losses as LS                      # the fused kernel's autograd node
     from geometry.pose_geometry import disp_to_depth
     from mcav import tape  # noqa: F401  (registers the resize entry points)
@@ -91,6 +92,6 @@ def multiscale_losses(tgt, refs, disparity, poses, K, inputs_are_depth=False):
         if Dt.shape[-1] != W:
             Dt, Dr = _ResizeFn.apply(Dt, H, W), _ResizeFn.apply(Dr, H, W)
         l0, _ = LS._WarpLossFn.apply(Dt.contiguous(), Dr.contiguous(), poses.contiguous(), tgt.contiguous(), refs[0].contiguous(),
-                                     refs[1].contiguous(), K.contiguous(), L.WL_INPUT_DEPTH | L.WL_NO_SMOOTH, tw)
+                                     refs[1].contiguous(), K.contiguous(), L.WL_INPUT_DEPTH | L.WL_NO_SMOOTH | (L.WL_SSIM if ssim else 0), tw)
         total = l0 if total is None else total + l0
     return [total, smooth_loss(depths[0])]

@@ -65,7 +65,10 @@ L.register({
     "mcav_add": (c_i, [c_p, c_p, c_sz, c_p, c_p]),
     "mcav_spatial_mean": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "mcav_spatial_mean_bwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
+    "mcav_upsample_nearest2x": (c_i, [c_p, c_sz, c_i, c_i, c_p, c_p]),
+    "mcav_upsample_nearest2x_bwd": (c_i, [c_p, c_sz, c_i, c_i, c_p, c_p]),
     "mcav_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_sz, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
+    "mcav_adam_step_dev": (c_i, [c_p, c_p, c_p, c_p, c_sz, c_f, c_f, c_f, c_p, c_p]),
     "mcav_kernel_timer_begin": (c_i, []),
     "mcav_kernel_timer_count": (c_i, []),
     "mcav_kernel_timer_end": (c_i, [c_p, c_i]),

@@ -3,8 +3,10 @@
 ConvBlock = reflection-padded 3x3 conv + ELU, Conv3x3 = reflection-padded 3x3 conv.  The modules own the parameters
 under the reference's attribute names (`.conv.conv.weight`, `.conv.weight`); standalone calls run the HIP conv kernel.
 """
+import torch
 import torch.nn as nn
 
+from mcav import lib as L
 from mcav import nn as N
 from mcav.holders import ConvParams
 from mcav.depthnet import dec_spec
@@ -40,5 +42,25 @@ class ConvBlock(nn.Module):
         return N.nhwc_to_nchw(N.conv_fwd(dec_spec(self.conv.conv), xin, act=N.ACT_ELU))
 
 
+class _Upsample2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = L.dev(x.contiguous(), "x")
+        B, C, h, w = x.shape
+        out = torch.empty((B, C, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+        L.check(L.lib().mcav_upsample_nearest2x(L.ptr(x), B * C, h, w, L.ptr(out), L.stream()), "mcav_upsample_nearest2x")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = L.dev(g.contiguous(), "grad")
+        B, C, H, W = g.shape
+        out = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=g.device)
+        L.check(L.lib().mcav_upsample_nearest2x_bwd(L.ptr(g), B * C, H // 2, W // 2, L.ptr(out), L.stream()), "mcav_upsample_nearest2x_bwd")
+        return out
+
+
 def upsample(x):
-    raise NotImplementedError("nearest x2 upsampling is fused into the decoder's conv gather (mcav/depthnet.py)")
+    """Upsample input tensor by a factor of 2 (reference layers.py:55-58: F.interpolate(x, scale_factor=2, mode="nearest")), NCHW.
+    Inside DepthDecoder the upsample is fused into the next conv's gather (mcav/depthnet.py); this is the standalone op."""
+    return _Upsample2xFn.apply(x)

@@ -54,6 +54,8 @@ class Trainer:
         self.epoch = 0
         self.step = 0
         self.verbose = bool(act.get('verbose', True))
+        self.use_hipgraph = bool(act.get('hipgraph', False))      # replay the step as one captured hipGraph per input shape
+        self._graphs = None
 
         self.depth_model = self.load_from_config(config, model_type='depth')
         self.pose_model = self.load_from_config(config, model_type='pose')
@@ -95,6 +97,9 @@ class Trainer:
         self.checkpoint = torch.load(self.save_path, map_location=self.device)
         self.depth_model.load_state_dict(self.checkpoint['dpth_mdl_state_dict'])
         self.pose_model.load_state_dict(self.checkpoint['pose_mdl_state_dict'])
+        # reference trainer.py:148: Adam's moments and step count resume too (FusedAdam copies them into its flat buffers)
+        self.model_optimizer.load_state_dict(self.checkpoint['optimizer_state_dict'])
+        self.model_optimizer.arena().bump()          # the weights changed through load_state_dict: packed copies are stale
         self.epoch = self.checkpoint['epoch']
         self.valid_acc = self.checkpoint['valid_acc']
 
@@ -139,8 +144,35 @@ class Trainer:
         for self.epoch in range(self.num_epochs):
             self.run_epoch()
 
+    def _graphed_step(self, samples):
+        """action.hipgraph: the same step replayed as one captured hipGraph per input shape (mcav/graph.py).  On one rank the Adam update is
+        inside the graph; with several ranks the all-reduce and Adam follow the replay eagerly."""
+        dev = self.device
+        tgt = samples['tgt'].to(dev, non_blocking=True)
+        ref_imgs = [img.to(dev, non_blocking=True) for img in samples['ref_imgs']]
+        K = samples['intrinsics'].to(dev, non_blocking=True)
+        if self._graphs is None:
+            from mcav.graph import StepGraphs
+
+            def fwd_bwd(tgt, ref0, ref1, K):
+                self.model_optimizer.zero_grad()
+                _, loss = self.process_batch({'tgt': tgt, 'ref_imgs': [ref0, ref1], 'intrinsics': K, 'groundtruth': None})
+                sum(loss).backward()
+                return tuple(loss)
+            buffers = list(self.depth_model.buffers()) + list(self.pose_model.buffers())
+            self._graphs = StepGraphs(fwd_bwd, self.model_optimizer, capture_adam=self.world == 1, buffers=buffers)
+        self.model_optimizer.grad_scale = 1.0 / self.world
+        self.loss = list(self._graphs(tgt, ref_imgs[0], ref_imgs[1], K))
+        if self.world > 1:
+            self.model_optimizer.grad_scale = mdist.allreduce_gradients(self.model_optimizer.arena())
+            self.model_optimizer.step()
+        self.step += 1
+        return None, self.loss
+
     def train_step(self, samples):
         """zero_grad -> process_batch -> backward -> (all-reduce) -> Adam  (reference trainer.py:261-266)."""
+        if self.use_hipgraph:
+            return self._graphed_step(samples)
         self.model_optimizer.zero_grad()
         outputs, self.loss = self.process_batch(samples)
         sum(self.loss).backward()
