@@ -29,6 +29,7 @@ import torch  # noqa: E402
 
 # conv FLOPs fwd per triplet at 192x640 R18 = 2 x 16.03 + 0.89 GF; fwd + dgrad + wgrad = 3x
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md); the bf16 conv stage also holds the fp32 launches the bf16 kernels do not cover
 PEAK_HBM_GBS = 8000.0
 TRAFFIC_JSON = os.path.join(REPO, "profiles", "r01_traffic.json")      # rocprofv3 PMC passes (tools/pmc_summary.py)
 
@@ -49,7 +50,13 @@ def measured_traffic(steps_in_profile=3):
     return conv / steps_in_profile, (warp[0] if warp and warp[0] > 0 else None)
 
 
-def workload_label(B, H, W, layers, ssim):
+def workload_label(B, H, W, layers, ssim, dtype="fp32"):
+    if dtype == "bf16":
+        if (B, H, W, layers, ssim) == (12, 192, 640, 18, False):
+            return "BASELINE.json configs[2] per-GPU shape"
+        if (B, layers, ssim) == (12, 18, False) and (H, W) == (256, 832):
+            return "BASELINE.json configs[4] per-GPU shape (256x832 steps)"
+        return "bf16 variant"
     if (B, H, W, layers, ssim) == (12, 192, 640, 18, False):
         return "BASELINE.json configs[1]"
     if (H, W, layers, ssim) == (320, 1024, 50, True):
@@ -66,13 +73,13 @@ def synthetic_samples(B, H, W, rank, step=0):
     return synthetic_batch(B, H, W, seed=1234 + 1000 * rank + step)
 
 
-def build(device, lr=1e-4, seed=0, depth_layers=18, ssim=False):
+def build(device, lr=1e-4, seed=0, depth_layers=18, ssim=False, dtype="fp32"):
     from models.depth.resnet_dispnet import DispResNet
     from models.pose.pose_net import PoseNet
     from mcav.optim import FusedAdam
     from losses import Losses
     torch.manual_seed(seed)
-    depth = DispResNet(depth_layers)
+    depth = DispResNet(depth_layers, dtype=torch.bfloat16 if dtype == "bf16" else None)      # bf16: the conv tiles of the depth net (98 % of the FLOPs)
     pose = PoseNet()
     pose.init_weights()
     depth.to(device).train()
@@ -164,6 +171,9 @@ def main():
     ap.add_argument("--depth-layers", type=int, default=18, help="ResNet depth of the encoder (18 = the metric's config; 50 = BASELINE.json configs[3])")
     ap.add_argument("--ssim", action="store_true", help="photometric term = 0.85 SSIM + 0.15 L1 (Losses(ssim=True); BASELINE.json configs[3] "
                                                         "stresses this kernel) instead of the reference's live L1")
+    ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32",
+                    help="bf16: the depth net's conv tiles on the bf16 MFMA (BASELINE.json configs[2] / [4]; fp32 accumulation, fp32 master weights and "
+                         "activations in HBM); the headline metric is quoted on fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--separate-passes", action="store_true", help="run the two depth passes as separate launch sets (default: stacked)")
@@ -190,7 +200,7 @@ def main():
     torch.cuda.set_device(device)
     B, H, W = args.batch, args.height, args.width
 
-    depth, pose, opt, crit = build(device, depth_layers=args.depth_layers, ssim=args.ssim)
+    depth, pose, opt, crit = build(device, depth_layers=args.depth_layers, ssim=args.ssim, dtype=args.dtype)
     mdist.broadcast_parameters(opt.arena())
     if os.environ.get("MCAV_DP_OVERLAP", "1") != "0":
         mdist.enable_overlap(opt.arena())          # N > 1: bucketed all-reduce behind the rest of backward (no-op on one rank)
@@ -229,11 +239,12 @@ def main():
 
     out = {"metric": "images/sec (fwd+bwd) KITTI 192x640 triplets, full training step", "value": round(value, 3), "unit": "images/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
            "config": {"workload": "%s: per-GPU batch=%d, %dx%d KITTI-shaped triplets, ResNet-%d depth encoder + 6-DoF PoseNet, "
-                                  "fp32, one step = 2x depth fwd + pose fwd + warp/%s/smooth loss + backward + Adam%s" %
-                                  (workload_label(B, H, W, args.depth_layers, args.ssim),
-                                   B, H, W, args.depth_layers, "SSIM+L1" if args.ssim else "L1", " + 1 RCCL all-reduce of the gradient arena" if world > 1 else ""),
+                                  "%s, one step = 2x depth fwd + pose fwd + warp/%s/smooth loss + backward + Adam%s" %
+                                  (workload_label(B, H, W, args.depth_layers, args.ssim, args.dtype),
+                                   B, H, W, args.depth_layers, "fp32" if args.dtype == "fp32" else "bf16 MFMA conv tiles (fp32 accumulate / storage)",
+                                   "SSIM+L1" if args.ssim else "L1", " + 1 RCCL all-reduce of the gradient arena" if world > 1 else ""),
                       "global_batch": B * world, "parallelism": "dp%d" % world},
            "loss": [round(float(l.detach()), 6) for l in loss], "hipgraph": bool(getattr(make_step, "graphed", False)),
            "ms_per_step_median": round(pct(0.5), 4), "ms_per_step_p10": round(pct(0.1), 4), "ms_per_step_p90": round(pct(0.9), 4)}
@@ -279,8 +290,11 @@ def main():
         conv_traffic, warp_traffic = measured_traffic() if (B, H, W) == (12, 192, 640) else (None, None)
         if args.ssim:
             warp_traffic = None
-        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": conv_traffic,
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        if args.dtype != "fp32":
+            conv_traffic = None
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(ach / peak, 4), "traffic": conv_traffic,
                            "traffic_note": "HBM bytes of the conv stage per step, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the rocprofv3 --pmc passes "
                                            "in profiles/r01_traffic.json (null when absent)",
                            "kernel": "conv stage = implicit-GEMM forward / adjoint, weight-gradient, halo and stencil kernels, all launches of one step; "

@@ -69,11 +69,18 @@ typedef struct mcav_igemm_desc {
                              * the low-resolution x1 instead of nine on the upsampled one (on the upsampled grid several taps of an output
                              * pixel read the same source pixel; per output parity class their filters are pre-summed).  Same result up to
                              * fp32 rounding of the filter sums; ignored where the launch does not qualify. */
+    int mma;                /* 0 = fp32 MFMA (exact fp32 products).  1 = bf16 MFMA tiles (BASELINE.json configs[2] / [4]): the source pixels are
+                             * rounded to bf16 on their way into LDS, the filter comes from w16, accumulation / epilogue / outputs stay fp32.
+                             * Launches the bf16 kernels do not cover (image stem, narrow high-resolution layers, 1-channel heads, pooled and
+                             * merged-tap forms) run the fp32 kernels with w; mcav_igemm_uses_bf16() tells which. */
+    const void* w16;        /* mma = 1: bf16 copy of the packed filter, same [Np][kh*kw][Kp] layout and row stride in ELEMENTS
+                             * (mcav_pack_weights_multi with transposed | 2, or mcav_f32_to_bf16 of a packed fp32 copy) */
 } mcav_igemm_desc;
 
 /* number of M-tiles (rows of `stats`) the launch will use with its chosen tile config */
 int mcav_igemm_mtiles(const mcav_igemm_desc* d);
 int mcav_igemm(const mcav_igemm_desc* d, void* stream);
+int mcav_igemm_uses_bf16(const mcav_igemm_desc* d);      /* 1: this descriptor (mma = 1, w16 set) runs on the bf16 MFMA kernels */
 
 /* Weight gradient: dw[n][tap][c] = sum_pix dy[pix, n] * src(pix, tap)[c], reduced over pixel splits and written
  * (accumulated if accumulate != 0) in OIHW [Cout][Cin][kh][kw] to dw_oihw.  The source is gathered exactly as in
@@ -99,9 +106,12 @@ typedef struct mcav_wgrad_desc {
      *    low-resolution pixels (2.25x fewer MACs); the 16 partial filters are un-merged into the 9 taps when the slab is reduced.  dbias must be
      *    NULL (the skip launch carries it).  Same result as one ordinary launch up to fp32 summation order. */
     int upm, Cin_total, ci_offset;
+    int mma;                /* 1: both operands rounded to bf16, reduction over pixels on the bf16 MFMA, fp32 slab / gradient (launches with
+                             * >= 32 output channels and 16-channel-aligned sources; others run the fp32 kernels) */
 } mcav_wgrad_desc;
 
 size_t mcav_wgrad_workspace_bytes(const mcav_wgrad_desc* d);
+int mcav_wgrad_uses_bf16(const mcav_wgrad_desc* d);
 int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* OIHW [Cout][Cin][kh][kw] -> packed forward filter [Np][taps][Kp] (transposed = 0)
@@ -114,6 +124,10 @@ int mcav_pack_weights(const float* w_oihw, int Cout, int Cin, int kh, int kw, in
  * where Kstride = taps * Kp rounded up to 16 and first_block is the running sum of mcav_pack_weights_blocks(...) over the
  * preceding records; nblocks = that sum over all records. */
 int mcav_pack_weights_multi(const void* items_dev, int nitems, int nblocks, void* stream);
+/* A record whose `transposed` has bit 1 set (2 or 3) writes its packed copy as bf16 (same layout, 2-byte elements): the filter copies
+ * of the bf16 MFMA kernels, re-derived from the fp32 master weights after every optimiser step in the same launch. */
+/* round-to-nearest-even fp32 -> bf16 of a flat buffer (the special packed copies: merged-tap adjoint filters) */
+int mcav_f32_to_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
 int mcav_pack_weights_blocks(int taps, int transposed, int Np, int Kp);   /* workgroups one record needs */
 /* Merged-tap copy of a 3x3 filter for mcav_igemm_desc.w_upmerge: packed [4 parity classes (py, px)][Np][4 merged taps (a, b)][C1] with
  * packed[cls][n][a*2+b][c] = sum of w[n][c][ky][kx] over ky in S(py, a), kx in S(px, b);  S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1},

@@ -109,32 +109,33 @@ def test_dispresnet50_vs_oracle():
     hip.to(DEV).train()
     ref.train()
     g = torch.Generator().manual_seed(78)
-    x = torch.randn(2, 3, 64, 128, generator=g)
-    coef = torch.randn(2, 1, 64, 128, generator=g)
+    x = torch.randn(4, 3, 64, 128, generator=g)          # batch 4: 32 samples per channel in layer4's BatchNorm (2x4 maps)
+    coef = torch.randn(4, 1, 64, 128, generator=g)
     want = ref(x)[0]
     (want * coef).sum().backward()
     got = hip(x.to(DEV))[0]
     assert rel_err(got, want) < 1e-3
     (got * coef.to(DEV)).sum().backward()
     rp = dict(ref.named_parameters())
-    for n, p in hip.named_parameters():
-        if rp[n].grad is None:
-            continue
-        e = float((p.grad.cpu() - rp[n].grad).norm() / rp[n].grad.norm().clamp_min(1e-20))
-        assert e < 5e-2, (n, e)      # 50+ BatchNorm/ReLU layers deep: mask flips accumulate towards the stem (measured 2.8e-2 at conv1)
-    # the arbiter under that bound: the same network in float64; HIP must be as close to it as the CPU fp32 oracle is
-    from arbiter import Verdicts, double_copy
+    # gradients: the fp64 arbiter (tests/arbiter.py) -- the same network in float64, as it is and on 1e-6-perturbed weights / input
+    from arbiter import Verdicts, double_copy, perturb_, perturb_tensor
     ref64 = double_copy(ref)
     ref64.zero_grad()
     out64 = ref64(x.double())[0]
     (out64 * coef.double()).sum().backward()
     r64 = dict(ref64.named_parameters())
-    v = Verdicts()
+    envs = []
+    for e in range(2):
+        re_ = perturb_(double_copy(ref), 1e-6, 900 + e)
+        re_.zero_grad()
+        (re_(perturb_tensor(x.double(), 1e-6, 950 + e))[0] * coef.double()).sum().backward()
+        envs.append(dict(re_.named_parameters()))
+    v = Verdicts(floor=2.5e-4)
     v.add("disparity", got, want, out64)
     for n, p in hip.named_parameters():
         if rp[n].grad is not None:
-            v.add(n, p.grad, rp[n].grad, r64[n].grad)
-    v.check("test_dispresnet50_vs_oracle")
+            v.add(n, p.grad, rp[n].grad, r64[n].grad, [env[n].grad for env in envs])
+    v.check("test_dispresnet50_vs_oracle", hip_abs=1e-1)      # ill-conditioned at random init (envelope up to 2e-2): the relative rule decides
     # the stacked two-pass form gives the same disparities
     hip2 = reinit_by_name(DispResNet50(), 77).to(DEV).train()
     a, b = hip2.forward_pair(x.to(DEV), x.flip(0).contiguous().to(DEV))

@@ -14,190 +14,10 @@
 #include <type_traits>
 #include <utility>
 
-#include "conv_gather.h"
+#include "conv_shared.h"
 #include "kernel_timer.h"
 
 namespace mcav {
-
-template <int BM_, int BN_, int WM_, int WN_, int MF_, int CK_ = 16>
-struct Tile {
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, MF = MF_;
-    static constexpr int KD = CK_;                            // K-tile depth of the forward/dgrad kernel (channels of one tap)
-    static constexpr int LD = CK_ + 4;                        // LDS row stride: 20 or 36 floats, both conflict-free for ds_read_b128
-    static constexpr int LPR = CK_ / 4;                       // lanes (16-byte columns) per operand row
-    static constexpr int RPP = 256 / LPR;                     // rows loaded per pass of the 256 threads
-    static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
-    static constexpr int TM = WM / MF, TN = WN / MF;         // MFMA tiles per wavefront
-    static constexpr int ACC = MF == 32 ? 16 : 4;             // accumulator registers per MFMA tile
-    using AccT = typename std::conditional<MF_ == 32, f32x16, f32x4>::type;
-    static constexpr int AROWS = BM / RPP;                    // A rows per thread per K-tile
-    static constexpr int BVECS = (BN * LPR + 255) / 256;      // B float4 per thread per K-tile
-    static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per workgroup");
-    static_assert(BM % RPP == 0, "BM multiple of the rows per pass");
-};
-
-using Tile128x64 = Tile<128, 64, 64, 32, 32>;
-using Tile64x64 = Tile<64, 64, 32, 32, 32>;
-using Tile256x32 = Tile<256, 32, 64, 32, 32>;
-using Tile256x16 = Tile<256, 16, 64, 16, 16>;
-using Tile128x128 = Tile<128, 128, 64, 64, 32>;
-using Tile64x16 = Tile<64, 16, 16, 16, 16>;
-using Tile128x32 = Tile<128, 32, 32, 32, 32>;
-using Tile128x64k32 = Tile<128, 64, 64, 32, 32, 32>;      // 32-deep K-tiles: twice the MFMA work per barrier / per load round trip
-using Tile128x128k32 = Tile<128, 128, 64, 64, 32, 32>;
-using Tile64x64k32 = Tile<64, 64, 32, 32, 32, 32>;
-using Tile64x64k64 = Tile<64, 64, 32, 32, 32, 64>;       // 64-deep: 32 MFMAs per wavefront between barriers
-using Tile32x64k32 = Tile<32, 64, 32, 16, 16, 32>;       // short tiles for the 6x20 maps of layer4 (M = 2880): twice the workgroups
-
-// f(integral_constant<int, 0>{}), ..., f(integral_constant<int, N - 1>{}): a loop whose index is a compile-time constant in the body
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
-// destination pixel of GEMM row m: returns false for padding rows.
-__device__ __forceinline__ bool decode_row(const IgemmParams& p, int m, int& n, int& dy, int& dx) {
-    if (p.g.mode == MCAV_G_ADJ_STRIDE2) {
-        // row blocks hold the parity classes in the order 3, 2, 1, 0: class (1,1) visits four taps of a 3x3 filter, class (0,0) one --
-        // the long tiles are dispatched first and the short ones fill the tail
-        const int blk = m / p.McP, r = m - blk * p.McP, cls = 3 - blk;
-        if (r >= p.Mc) return false;
-        const int Hc = (p.Hd + 1) >> 1, Wc = (p.Wd + 1) >> 1;
-        n = r / (Hc * Wc);
-        const int q = r - n * (Hc * Wc);
-        const int y2 = q / Wc, x2 = q - y2 * Wc;
-        dy = 2 * y2 + (cls >> 1);
-        dx = 2 * x2 + (cls & 1);
-        return dy < p.Hd && dx < p.Wd;
-    }
-    if (m >= p.M) return false;
-    if (p.upm) {             // merged-tap upsample: a tile holds one output parity class (py, px); the four classes of one image region are
-                             // consecutive tiles (same XCD, same time: the skip tensor's pixels they all read stay in L2)
-        const int blk = m / p.bm, cls = blk & 3, r = (blk >> 2) * p.bm + (m - blk * p.bm);
-        if (r >= p.Mc) return false;
-        const int Hc = p.Hd >> 1, Wc = p.Wd >> 1;
-        n = r / (Hc * Wc);
-        const int q = r - n * (Hc * Wc);
-        const int y2 = q / Wc, x2 = q - y2 * Wc;
-        dy = 2 * y2 + (cls >> 1);
-        dx = 2 * x2 + (cls & 1);
-        return true;
-    }
-    if (p.groups > 1) {      // group-major rows, each group padded to whole tiles
-        const int grp = m / p.McP, r = m - grp * p.McP;
-        if (r >= p.Mc) return false;
-        const int hw = p.Hd * p.Wd, ng = r / hw, q = r - ng * hw;
-        n = grp * (p.g.B / p.groups) + ng;
-        dy = q / p.Wd;
-        dx = q - dy * p.Wd;
-        return true;
-    }
-    if (p.pool) {
-        const int blk = m >> 2, q = m & 3;
-        const int Hh = p.Hd >> 1, Wh = p.Wd >> 1;
-        n = blk / (Hh * Wh);
-        const int r = blk - n * (Hh * Wh);
-        const int y2 = r / Wh, x2 = r - y2 * Wh;
-        dy = 2 * y2 + (q >> 1);
-        dx = 2 * x2 + (q & 1);
-        return true;
-    }
-    n = m / (p.Hd * p.Wd);
-    const int r = m - n * (p.Hd * p.Wd);
-    dy = r / p.Wd;
-    dx = r - dy * p.Wd;
-    return true;
-}
-
-// Kernel kinds (compile-time specialisations of the A-operand gather; the generic one handles everything):
-//   K_FAST    DIRECT gather, every source tensor has a multiple of 4 channels: one source pixel per (row, tap), offsets cached
-//             per tap, BRANCH-FREE 16-byte loads (invalid rows load from offset 0 and are zeroed by a select) so that the
-//             compiler keeps all loads of a tile in flight behind one counted s_waitcnt
-//   K_REFLADJ adjoint of the 3x3 reflection-padded conv: same as K_FAST away from the image border; wavefronts that touch the
-//             border (wave-uniform test) take 4 predicated loads per row instead of 1
-//   K_GENERIC any mode / any channel count (image stem, stride-2 adjoint, 1-channel disparity maps)
-enum { K_FAST = 0, K_REFLADJ = 1, K_GENERIC = 2 };
-
-// Epilogue shared by the forward/dgrad kernels: bias, activation, optional act'(aux) factor and addend, 2x2 sum-pool, channel-range
-// store, BatchNorm column sums.  C/D layout: 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
-//                                            16x16: col = lane & 15, row = 4 (lane >> 4) + r.   Registers 4q..4q+3 are 4 consecutive rows.
-template <class T>
-__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, typename T::AccT (&acc)[T::TM][T::TN], const int* s_out,
-                                               float (*s_stat)[2][T::BN], int tid, int wm0, int wn0, int n0, int mt) {
-    constexpr int BN = T::BN;
-    const int lane = tid & 63, wave = tid >> 6;
-    constexpr int MF = T::MF;
-    const int ccol = lane & (MF - 1);
-    float ssum[T::TN], ssq[T::TN];
-#pragma unroll
-    for (int j = 0; j < T::TN; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < T::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < T::TN; ++j) {
-            const int nl = n0 + wn0 + j * MF + ccol;          // column within this launch
-            const bool ncol = nl < p.n_count;
-            const float bv = (p.bias && ncol) ? p.bias[p.n_begin + nl] : 0.f;
-#pragma unroll
-            for (int q = 0; q < T::ACC / 4; ++q) {
-                const int rbase = wm0 + i * MF + (MF == 32 ? 8 * q + 4 * (lane >> 5) : 4 * (lane >> 4));
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_fwd(acc[i][j][4 * q + e] + bv, p.act);
-                if (p.pool) {
-                    const int o = s_out[rbase];
-                    if (o >= 0 && ncol) {
-                        float s = (v[0] + v[1]) + (v[2] + v[3]);
-                        const size_t off = (size_t)o * p.Cd + p.y_choff + nl;
-                        if (p.dact_aux) s *= act_bwd(p.dact_aux[off], p.dact);
-                        if (p.addend) s += p.addend[off];
-                        p.y[off] = s;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int o = s_out[rbase + e];
-                        if (o >= 0 && ncol) {
-                            float s = v[e];
-                            const size_t off = (size_t)o * p.Cd + p.y_choff + nl;
-                            if (p.dact_aux) s *= act_bwd(p.dact_aux[off], p.dact);
-                            if (p.addend) s += p.addend[off];
-                            p.y[off] = s;
-                            ssum[j] += s;
-                            ssq[j] += s * s;
-                        }
-                    }
-                }
-            }
-        }
-    if (p.stats) {
-        // column sums over this workgroup's rows: lanes holding the same column, then the wavefronts stacked along M
-#pragma unroll
-        for (int j = 0; j < T::TN; ++j) {
-            if (MF == 32) {
-                ssum[j] += __shfl_xor(ssum[j], 32, 64);
-                ssq[j] += __shfl_xor(ssq[j], 32, 64);
-            } else {
-                ssum[j] += __shfl_xor(ssum[j], 16, 64); ssq[j] += __shfl_xor(ssq[j], 16, 64);
-                ssum[j] += __shfl_xor(ssum[j], 32, 64); ssq[j] += __shfl_xor(ssq[j], 32, 64);
-            }
-            if (lane < MF) {
-                s_stat[wave / T::WAVES_N][0][wn0 + j * MF + lane] = ssum[j];
-                s_stat[wave / T::WAVES_N][1][wn0 + j * MF + lane] = ssq[j];
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < 2 * BN; e += 256) {
-            const int which = e / BN, col = e - which * BN;
-            if (n0 + col < p.n_count) {
-                float s = 0.f;
-#pragma unroll
-                for (int wmi = 0; wmi < T::WAVES_M; ++wmi) s += s_stat[wmi][which][col];
-                p.stats[((size_t)mt * 2 + which) * p.n_count + n0 + col] = s;
-            }
-        }
-    }
-}
 
 template <class T, int KIND>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
@@ -521,7 +341,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 //   * the accumulators never leave their registers (no conditional around the MFMAs).
 // fp32 MFMA and the VALU share the SIMD's FMA datapath on gfx950 (equal peak rates): an address instruction in the loop costs
 // MFMA time, and the previous loop spent about a third of its issue slots on them.
-constexpr int TAB_TAPS = 16;     // 3x3 filters, and the 4x4 stride-2 form of the pooled upsample adjoint
 
 // REFL = the adjoint of the 3x3 reflection-padded conv (decoder dgrad): away from the image border it is the plain
 // correlation (sy = dy + 1 - ky); a wavefront that owns rows within two pixels of the border (wave-uniform test) issues up
@@ -982,25 +801,6 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
 // ------------------------------------------------------------------------------------------------ weight gradient
 // out[kflat, n] = sum_pix A[pix, kflat] * dy[pix, n]: GEMM rows = flattened (tap, c) of the filter, columns = output
 // channels, reduction over pixels (split across workgroups; partial tiles go to a slab and are summed in fixed order).
-struct WgradParams {
-    GatherSrc g;
-    int kh, kw, Kp, taps, Ktot;   // Ktot = taps * Kp (GEMM rows)
-    const float* dy;
-    int Hd, Wd, Cdy, dy_choff, Cout;
-    int CoutLoad;                  // Cout rounded up to 4 when dy physically has those (zero) channels
-    int Mpix;                      // B * Hd * Wd
-    int splits, pix_per_split;     // pixel ranges per workgroup (multiple of KP)
-    int mtiles, ntiles;
-    float* slab;                   // [splits][Ktot + 1][slabN]; row Ktot holds the per-split column sums of dy (bias gradient)
-    int slabN;                     // row stride of the slab (Cout rounded up to 16)
-    int want_bias;
-    int tab_cht_log2;              // wgrad_tab_kernel: log2 of the tiles per table chunk (>= 20: the whole split is one chunk)
-    int upm;                       // merged-tap upsample (mcav_wgrad_desc.upm): rows = 16 (class, merged tap) x Kp, pixels = LOW-resolution ones
-    int Hf, Wf;                    // upm: full-resolution size of dy (Hd, Wd hold the low-resolution one)
-};
-
-constexpr int KP = 32;   // pixels per K-tile of the wgrad GEMM
-
 template <class T, int KIND>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     constexpr int BM = T::BM, BN = T::BN;
@@ -1253,7 +1053,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 //   * per A load the loop does one ds_read_b32 (prefetched a tile ahead) and one v_add (the lane's channel offset);
 //   * dy rows advance linearly: their loads use the instruction's SCALAR offset, and the buffer resource ends at this
 //     split's last pixel, so the ragged last tile needs no masking.
-constexpr int WG_TABCAP = 4096;
 
 // UPM: the weight gradient of the upsampled half of conv(cat(up2(a), skip)) in merged-tap form (see mcav_wgrad_desc.upm): the K
 // dimension runs over LOW-resolution pixels, a row tile belongs to one output parity class (py, px) and one or more of its 4 merged
@@ -1691,7 +1490,7 @@ constexpr int PK_CO = 64;
 __host__ __device__ inline int pack_ci_tile(int taps) { const int t = 192 / taps; return t < 1 ? 1 : (t > 8 ? 8 : t); }
 
 __host__ __device__ inline int pack_blocks(int transposed, int taps, int Np, int Kp) {
-    if (!transposed) return Np;
+    if (!(transposed & 1)) return Np;
     const int ct = pack_ci_tile(taps);
     return ((Np + ct - 1) / ct) * ((Kp + PK_CO - 1) / PK_CO);
 }
@@ -1703,7 +1502,10 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem*
         const int mid = (lo + hi + 1) >> 1;
         if (items[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
-    const PackItem it = items[lo];
+    PackItem it = items[lo];
+    const bool to_bf16 = (it.transposed & 2) != 0;      // bit 1: the destination holds bf16 (the filter copies of the bf16 MFMA kernels)
+    it.transposed &= 1;
+    __bf16* const dst16 = reinterpret_cast<__bf16*>(it.dst);
     const int bl = blockIdx.x - it.first_block, tid = threadIdx.x;
     if (!it.transposed) {
         const int n = bl, run = it.Cin * it.taps;
@@ -1718,7 +1520,8 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem*
             const int tap = kf / it.Kp, k = kf - tap * it.Kp;
             float v = 0.f;
             if (n < it.Cout && tap < it.taps && k < it.Cin) v = staged ? buf[k * it.taps + tap] : it.src[((size_t)n * it.Cin + k) * it.taps + tap];
-            drow[kf] = v;
+            if (to_bf16) dst16[(size_t)n * it.Kstride + kf] = (__bf16)v;
+            else drow[kf] = v;
         }
         return;
     }
@@ -1735,7 +1538,11 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem*
     for (int e = tid; e < PK_CO * run; e += 256) {
         const int q = e / PK_CO, co = e - q * PK_CO;      // q = r * taps + tap
         const int r = q / it.taps, tap = q - r * it.taps;
-        if (ci0 + r < it.Np && co0 + co < it.Kp) it.dst[(size_t)(ci0 + r) * it.Kstride + tap * it.Kp + co0 + co] = buf[co * ld + q];
+        if (ci0 + r < it.Np && co0 + co < it.Kp) {
+            const size_t o = (size_t)(ci0 + r) * it.Kstride + tap * it.Kp + co0 + co;
+            if (to_bf16) dst16[o] = (__bf16)buf[co * ld + q];
+            else it.dst[o] = buf[co * ld + q];
+        }
     }
 }
 
@@ -1757,7 +1564,7 @@ inline int pick_tile(const mcav_igemm_desc* d, long M) {
     return t128x64 >= 1024 ? 1 : 2;
 }
 
-inline void tile_dims(int id, int& BM, int& BN) {
+void tile_dims(int id, int& BM, int& BN) {
     switch (id) {
         case 1: BM = 128; BN = 64; break;
         case 2: BM = 64; BN = 64; break;
@@ -1774,7 +1581,7 @@ inline void tile_dims(int id, int& BM, int& BN) {
     }
 }
 
-inline bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
+bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
     if (!d || !d->x1 || !d->w || !d->y) return false;
     if (d->B <= 0 || d->Hs <= 0 || d->Ws <= 0 || d->Hd <= 0 || d->Wd <= 0 || d->C1 <= 0 || d->C2 < 0) return false;
     if (d->C2 > 0 && !d->x2) return false;
@@ -1866,6 +1673,9 @@ MCAV_EXPORT int mcav_igemm_mtiles(const mcav_igemm_desc* d) {
 }
 
 bool mcav_try_halo(const mcav_igemm_desc* d, hipStream_t s);      // conv_halo.hip: narrow high-resolution 3x3 layers (forward and reflect-adjoint)
+int mcav_bf16_igemm(const mcav_igemm_desc* d, hipStream_t s);      // conv_bf16.hip: 1 = not eligible
+bool mcav_bf16_wgrad_plan(const mcav_wgrad_desc* d, mcav::WgradPlan& pl);
+void mcav_bf16_wgrad_launch(const mcav::WgradParams& p, hipStream_t s);
 
 MCAV_EXPORT int mcav_igemm(const mcav_igemm_desc* d, void* stream) {
     IgemmParams p;
@@ -1873,6 +1683,10 @@ MCAV_EXPORT int mcav_igemm(const mcav_igemm_desc* d, void* stream) {
     if (!fill_params(d, p, tile)) return MCAV_E_INVALID;
     hipStream_t s = as_stream(stream);
     if (mcav_try_halo(d, s)) return launch_status();
+    if (d->mma == 1) {                                   // bf16 MFMA tiles (conv_bf16.hip) where the launch qualifies, else the fp32 kernels below
+        const int rc = mcav_bf16_igemm(d, s);
+        if (rc != 1) return rc;
+    }
     switch (tile) {
         case 1: launch_igemm<Tile128x64>(p, s); break;
         case 2: launch_igemm<Tile64x64>(p, s); break;
@@ -1893,21 +1707,12 @@ MCAV_EXPORT int mcav_igemm(const mcav_igemm_desc* d, void* stream) {
 
 namespace mcav {
 
-struct WgradPlan {
-    WgradParams p;
-    int tile;
-    bool use_tab;
-    bool use_halo;
-    size_t slab_bytes, pre_bytes;
-    int ci_t, groups, per_group;
-};
-
 }  // namespace mcav
 int mcav_halo_wgrad_splits(const mcav_wgrad_desc* d);
 void mcav_halo_wgrad_launch(const mcav_wgrad_desc* d, float* slab, int slabN, int splits, hipStream_t s);
 namespace mcav {
 
-inline bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
+bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     if (!d || !d->x1 || !d->dy || !d->dw_oihw) return false;
     if (d->B <= 0 || d->Hs <= 0 || d->Ws <= 0 || d->Hd <= 0 || d->Wd <= 0 || d->C1 <= 0 || d->C2 < 0 || d->Cout <= 0 || d->Cin <= 0) return false;
     if (d->C2 > 0 && (!d->x2 || d->C1 % 4 != 0)) return false;
@@ -2017,17 +1822,24 @@ inline void launch_wgrad(const WgradParams& p, bool use_tab, hipStream_t s) {
 
 MCAV_EXPORT size_t mcav_wgrad_workspace_bytes(const mcav_wgrad_desc* d) {
     WgradPlan pl;
-    if (!plan_wgrad(d, pl)) return 0;
+    if (!(d && d->mma == 1 && mcav_bf16_wgrad_plan(d, pl)) && !plan_wgrad(d, pl)) return 0;
     return pl.slab_bytes + pl.pre_bytes;
+}
+
+MCAV_EXPORT int mcav_wgrad_uses_bf16(const mcav_wgrad_desc* d) {
+    WgradPlan pl;
+    return d && d->mma == 1 && mcav_bf16_wgrad_plan(d, pl);
 }
 
 MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
     WgradPlan pl;
-    if (!plan_wgrad(d, pl) || !workspace) return MCAV_E_INVALID;
+    const bool bf16 = d && d->mma == 1 && mcav_bf16_wgrad_plan(d, pl);      // bf16 MFMA tiles where the launch qualifies (conv_bf16.hip)
+    if ((!bf16 && !plan_wgrad(d, pl)) || !workspace) return MCAV_E_INVALID;
     if (workspace_bytes < pl.slab_bytes + pl.pre_bytes) return MCAV_E_WORKSPACE;
     hipStream_t s = as_stream(stream);
     pl.p.slab = reinterpret_cast<float*>(workspace);
-    if (pl.use_halo) mcav_halo_wgrad_launch(d, pl.p.slab, pl.p.slabN, pl.p.splits, s);
+    if (bf16) mcav_bf16_wgrad_launch(pl.p, s);
+    else if (pl.use_halo) mcav_halo_wgrad_launch(d, pl.p.slab, pl.p.slabN, pl.p.splits, s);
     else switch (pl.tile) {
         case 1: launch_wgrad<Tile128x64>(pl.p, pl.use_tab, s); break;
         case 2: launch_wgrad<Tile64x64>(pl.p, pl.use_tab, s); break;

@@ -23,7 +23,7 @@ class IgemmDesc(ctypes.Structure):
                 ("mode", c_i), ("stride", c_i), ("sign", c_i), ("offset", c_i), ("pad_mode", c_i),
                 ("y", c_p), ("Hd", c_i), ("Wd", c_i), ("Cd", c_i), ("n_begin", c_i), ("n_count", c_i), ("y_choff", c_i),
                 ("bias", c_p), ("act", c_i), ("dact_aux", c_p), ("dact", c_i), ("addend", c_p), ("pool", c_i), ("stats", c_p),
-                ("tile", c_i), ("groups", c_i), ("w_upmerge", c_p)]
+                ("tile", c_i), ("groups", c_i), ("w_upmerge", c_p), ("mma", c_i), ("w16", c_p)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -31,12 +31,16 @@ class WgradDesc(ctypes.Structure):
                 ("kh", c_i), ("kw", c_i), ("Kp", c_i),
                 ("mode", c_i), ("stride", c_i), ("sign", c_i), ("offset", c_i), ("pad_mode", c_i),
                 ("dy", c_p), ("Hd", c_i), ("Wd", c_i), ("Cdy", c_i), ("dy_choff", c_i), ("Cout", c_i), ("Cin", c_i),
-                ("dw_oihw", c_p), ("accumulate", c_i), ("dbias", c_p), ("tile", c_i), ("upm", c_i), ("Cin_total", c_i), ("ci_offset", c_i)]
+                ("dw_oihw", c_p), ("accumulate", c_i), ("dbias", c_p), ("tile", c_i), ("upm", c_i), ("Cin_total", c_i), ("ci_offset", c_i),
+                ("mma", c_i)]
 
 
 L.register({
     "mcav_igemm_mtiles": (c_i, [ctypes.POINTER(IgemmDesc)]),
     "mcav_igemm": (c_i, [ctypes.POINTER(IgemmDesc), c_p]),
+    "mcav_igemm_uses_bf16": (c_i, [ctypes.POINTER(IgemmDesc)]),
+    "mcav_wgrad_uses_bf16": (c_i, [ctypes.POINTER(WgradDesc)]),
+    "mcav_f32_to_bf16": (c_i, [c_p, c_p, c_sz, c_p]),
     "mcav_wgrad_workspace_bytes": (c_sz, [ctypes.POINTER(WgradDesc)]),
     "mcav_wgrad": (c_i, [ctypes.POINTER(WgradDesc), c_p, c_sz, c_p]),
     "mcav_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
@@ -131,52 +135,53 @@ class _PackItem(ctypes.Structure):
                 ("Kstride", c_i), ("first_block", c_i)]
 
 
+MMA_FP32, MMA_BF16 = 0, 1
+_KINDS = {"f": (False, False), "b": (True, False), "f16": (False, True), "b16": (True, True)}      # kind -> (transposed, bf16)
+
+
 class PackRegistry:
     """Every packed filter copy that has been requested so far.  After an optimiser step all of them are stale; the first one
     that is asked for re-derives ALL of them with one mcav_pack_weights_multi launch (instead of ~80 small ones)."""
 
     def __init__(self):
-        self.entries = []          # (spec, transposed)
+        self.entries = []          # (weakref to spec, kind)
         self.table = None
         self.nblocks = 0
         self.signature = None
 
-    def add(self, spec, transposed):
+    def add(self, spec, kind):
         import weakref
-        self.entries.append((weakref.ref(spec), transposed))
+        self.entries.append((weakref.ref(spec), kind))
         self.table = None
 
     def _build(self, device, live):
         items = (_PackItem * len(live))()
         blk = 0
-        for it, (spec, tr) in zip(items, live):
-            buf = spec._bwd if tr else spec._fwd
+        for it, (spec, kind) in zip(items, live):
+            tr, h = _KINDS[kind]
+            buf = spec._packs[kind]
             np_, kp_ = (up16(spec.cin), up16(spec.cout)) if tr else (spec.np, spec.kp)
             it.src, it.dst = spec.weight.data_ptr(), buf.data_ptr()
-            it.Cout, it.Cin, it.taps, it.transposed = spec.cout, spec.cin, spec.kh * spec.kw, int(tr)
+            it.Cout, it.Cin, it.taps, it.transposed = spec.cout, spec.cin, spec.kh * spec.kw, int(tr) | (2 if h else 0)
             it.Np, it.Kp, it.Kstride, it.first_block = np_, kp_, buf.shape[1], blk
             blk += L.lib().mcav_pack_weights_blocks(it.taps, int(tr), np_, kp_)
         raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
         self.table = raw.to(device)
         self.nblocks = blk
 
-
     def repack_all(self, device):
-        self.entries = [(r, tr) for r, tr in self.entries if r() is not None]          # drop specs of deleted modules
-        live = [(r(), tr) for r, tr in self.entries]
-        live = [(s, tr) for s, tr in live if s is not None and s.weight.device == device and (s._bwd if tr else s._fwd) is not None]
+        self.entries = [(r, k) for r, k in self.entries if r() is not None]          # drop specs of deleted modules
+        live = [(r(), k) for r, k in self.entries]
+        live = [(s, k) for s, k in live if s is not None and s.weight.device == device and s._packs.get(k) is not None]
         if not live:
             return
-        sig = tuple((s.weight.data_ptr(), (s._bwd if tr else s._fwd).data_ptr()) for s, tr in live)
+        sig = tuple((s.weight.data_ptr(), s._packs[k].data_ptr()) for s, k in live)
         if self.table is None or sig != self.signature or self.table.device != device:
             self._build(device, live)
             self.signature = sig
         L.check(L.lib().mcav_pack_weights_multi(P(self.table), len(live), self.nblocks, L.stream()), "mcav_pack_weights_multi")
-        for s, tr in live:
-            if tr:
-                s._key_b = s._key()
-            else:
-                s._key_f = s._key()
+        for s, k in live:
+            s._keys[k] = s._key()
 
 
 PACKS = PackRegistry()
@@ -185,11 +190,11 @@ PACKS = PackRegistry()
 def refresh_packed_weights(device):
     """Re-derive every stale packed filter copy NOW, on the current stream.  Call before forking work onto other streams: the lazy
     refresh inside packed_fwd()/packed_bwd() runs on whichever stream asks first, which the other streams would not wait for."""
-    for ref, tr in PACKS.entries:
+    for ref, k in PACKS.entries:
         s = ref()
         if s is None or s.weight.device != device:
             continue
-        if (s._key_b if tr else s._key_f) != s._key():
+        if s._keys.get(k) != s._key():
             PACKS.repack_all(device)
             return
 
@@ -204,27 +209,39 @@ class ConvSpec:
         self.smallc = smallc                             # the 3-channel image stem: source is NHWC4
         self.kp = 4 if smallc else up16(self.cin)        # K padding of the forward filter
         self.np = up16(self.cout)
-        self._fwd = self._bwd = None
-        self._key_f = self._key_b = None
+        self.mma = MMA_FP32                              # MMA_BF16: eligible launches run the bf16 MFMA kernels (set_compute_dtype)
+        self._packs, self._keys = {}, {}                 # kind ("f", "b", "f16", "b16") -> packed copy / the weight version it was made from
 
     def _key(self):
         w = self.weight
         return (w.data_ptr(), w._version, getattr(w, "_mcav_epoch", lambda: 0)())
 
-    def packed_fwd(self):
+    def _packed(self, kind):
+        tr, h = _KINDS[kind]
         key = self._key()
-        if self._fwd is None or self._key_f != key or self._fwd.device != self.weight.device:
+        buf = self._packs.get(kind)
+        if buf is None or self._keys.get(kind) != key or buf.device != self.weight.device:
             taps = self.kh * self.kw
-            kstride = up16(taps * self.kp)
-            if self._fwd is None or self._fwd.device != self.weight.device:
-                self._fwd = empty((self.np, kstride), self.weight)
-                L.check(L.lib().mcav_pack_weights(P(self.weight), self.cout, self.cin, self.kh, self.kw, 0, P(self._fwd), self.np, self.kp,
-                                                  L.stream()), "mcav_pack_weights")
-                self._key_f = key
-                PACKS.add(self, False)
-            else:
-                PACKS.repack_all(self.weight.device)       # one launch refreshes every registered copy (this one included)
-        return self._fwd
+            if buf is None or buf.device != self.weight.device:
+                shape = (up16(self.cin), taps * up16(self.cout)) if tr else (self.np, up16(taps * self.kp))
+                buf = torch.empty(shape, dtype=torch.bfloat16 if h else torch.float32, device=self.weight.device)
+                self._packs[kind] = buf
+                PACKS.add(self, kind)
+            PACKS.repack_all(self.weight.device)           # one launch refreshes every registered copy (this one included)
+        return self._packs[kind]
+
+    def packed_fwd(self):
+        return self._packed("f")
+
+    def packed_bwd(self):
+        """Data-gradient filter: rows = input channels (padded to 16), K = output channels (padded to 16)."""
+        return self._packed("b")
+
+    def packed_fwd16(self):
+        return self._packed("f16")
+
+    def packed_bwd16(self):
+        return self._packed("b16")
 
     def packed_upmerge(self, c1):
         """Merged-tap copy for conv(cat(up2(x1), x2)) with reflection padding: [4 classes][Np][4 taps][c1] pre-summed filters of the
@@ -238,33 +255,55 @@ class ConvSpec:
             self._key_u = key
         return self._upm
 
-    def packed_upmerge_adj(self, c1):
-        """[up16(c1)][16 taps][up16(cout)]: the 4x4 stride-2 filter of the pooled upsample adjoint (mcav_pack_weights_upmerge_adj)."""
+    def packed_upmerge_adj(self, c1, bf16=False):
+        """[up16(c1)][16 taps][up16(cout)]: the 4x4 stride-2 filter of the pooled upsample adjoint (mcav_pack_weights_upmerge_adj);
+        bf16: its rounded copy for the bf16 MFMA kernel (mcav_f32_to_bf16)."""
         key = self._key() + (c1,)
         if getattr(self, "_upa", None) is None or self._key_ua != key or self._upa.device != self.weight.device:
             npd, kpd = up16(c1), up16(self.cout)
             if getattr(self, "_upa", None) is None or self._upa.device != self.weight.device or self._upa.shape[0] != npd:
                 self._upa = empty((npd, 16 * kpd), self.weight)
+                self._upa16 = None
             L.check(L.lib().mcav_pack_weights_upmerge_adj(P(self.weight), self.cout, self.cin, c1, P(self._upa), npd, kpd, L.stream()),
                     "mcav_pack_weights_upmerge_adj")
             self._key_ua = key
-        return self._upa
+            self._key_ua16 = None
+        if not bf16:
+            return self._upa
+        if getattr(self, "_upa16", None) is None or self._key_ua16 != key:
+            if getattr(self, "_upa16", None) is None:
+                self._upa16 = torch.empty(self._upa.shape, dtype=torch.bfloat16, device=self._upa.device)
+            L.check(L.lib().mcav_f32_to_bf16(P(self._upa), P(self._upa16), self._upa.numel(), L.stream()), "mcav_f32_to_bf16")
+            self._key_ua16 = key
+        return self._upa16
 
-    def packed_bwd(self):
-        """Data-gradient filter: rows = input channels (padded to 16), K = output channels (padded to 16)."""
-        key = self._key()
-        if self._bwd is None or self._key_b != key or self._bwd.device != self.weight.device:
-            taps = self.kh * self.kw
-            npd, kpd = up16(self.cin), up16(self.cout)
-            if self._bwd is None or self._bwd.device != self.weight.device:
-                self._bwd = empty((npd, taps * kpd), self.weight)
-                L.check(L.lib().mcav_pack_weights(P(self.weight), self.cout, self.cin, self.kh, self.kw, 1, P(self._bwd), npd, kpd, L.stream()),
-                        "mcav_pack_weights")
-                self._key_b = key
-                PACKS.add(self, True)
-            else:
-                PACKS.repack_all(self.weight.device)
-        return self._bwd
+
+def set_compute_dtype(module, dtype):
+    """Opt-in bf16 MFMA conv tiles for every convolution of `module` (BASELINE.json configs[2] / [4]): torch.bfloat16 / "bf16" switches the
+    launches the bf16 kernels cover (csrc/conv_bf16.hip) to bf16 operands with fp32 accumulation; torch.float32 / "fp32" switches back.
+    Master weights, activations in HBM, BatchNorm statistics and gradients stay fp32."""
+    bf16 = dtype in (torch.bfloat16, "bf16", "bfloat16")
+    if not bf16 and dtype not in (torch.float32, "fp32", "f32", "float32", None):
+        raise L.MCAVError("compute dtype must be fp32 or bf16, got %r" % (dtype,))
+    for m in module.modules():
+        if hasattr(m, "weight") and getattr(m, "weight") is not None and m.weight.dim() == 4:
+            m._mcav_mma = MMA_BF16 if bf16 else MMA_FP32
+            spec = getattr(m, "_mcav_spec", None)
+            if spec is not None:
+                spec.mma = m._mcav_mma
+    return module
+
+
+def _weights_for(spec, d, transposed):
+    """Fills d.w / d.w16 / d.mma of an IgemmDesc whose geometry is already set: the bf16 copy where the launch runs on the bf16 kernels."""
+    if spec.mma == MMA_BF16:
+        d.mma, d.w16, d.w = 1, d.x1, d.x1                 # placeholders: the eligibility test looks at the geometry only
+        if L.lib().mcav_igemm_uses_bf16(ctypes.byref(d)):
+            w16 = spec.packed_bwd16() if transposed else spec.packed_fwd16()
+            d.w16 = d.w = P(w16)                           # (w is never read on the bf16 path; it only has to be non-null)
+            return
+    d.mma, d.w16 = 0, None
+    d.w = P(spec.packed_bwd() if transposed else spec.packed_fwd())
 
 
 def out_size(n, k, s, p):
@@ -282,7 +321,6 @@ def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0, gr
     d = IgemmDesc()
     d.x1, d.x2 = P(x1), P(x2)
     d.B, d.Hs, d.Ws, d.C1, d.C2, d.up1 = B, Hs, Ws, C1, C2, int(up1)
-    d.w = P(spec.packed_fwd())
     d.kh, d.kw, d.Np, d.Kp = spec.kh, spec.kw, spec.np, spec.kp
     d.mode = G_SMALLC if spec.smallc else G_DIRECT
     d.stride, d.sign, d.offset, d.pad_mode = spec.stride, 1, -spec.pad, spec.pad_mode
@@ -290,8 +328,9 @@ def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0, gr
     d.bias, d.act = P(spec.bias), act
     d.tile = tile
     d.groups = groups if stats else 1
+    _weights_for(spec, d, False)
     if (up1 and x2 is not None and not stats and spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad == 1
-            and spec.pad_mode == PAD_REFLECT and C1 % 16 == 0 and not (tile >> 11) & 1):
+            and spec.pad_mode == PAD_REFLECT and C1 % 16 == 0 and not (tile >> 11) & 1 and not d.mma):
         d.w_upmerge = P(spec.packed_upmerge(C1))       # the upsampled part as 4 merged taps on the low-resolution x1 (tile bit 11: off)
     h = L.lib()
     slab = None
@@ -320,12 +359,10 @@ def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=N
             and spec.pad_mode == PAD_REFLECT and n_count % 16 == 0 and n_count >= UPMERGE_ADJ_MIN_N and Cout == up16(spec.cout)
             and Cout % 32 == 0 and Hs % 2 == 0 and Ws % 2 == 0 and not (tile >> 12) & 1):
         return _dgrad_upsample_merged(spec, dy, (Hs, Ws), n_count, dact_aux, dact, addend, tile)
-    wb = spec.packed_bwd()
     y = out if out is not None else empty((B, Hs // 2 if pool else Hs, Ws // 2 if pool else Ws, n_count), dy)
     d = IgemmDesc()
     d.x1, d.x2 = P(dy), None
     d.B, d.Hs, d.Ws, d.C1, d.C2, d.up1 = B, Hd, Wd, Cout, 0, 0       # Cout = channels physically in dy (may be zero-padded past spec.cout)
-    d.w = P(wb)
     d.kh, d.kw, d.Np, d.Kp = spec.kh, spec.kw, up16(spec.cin), up16(spec.cout)
     if spec.stride == 1:
         if spec.pad_mode == PAD_REFLECT:
@@ -341,6 +378,7 @@ def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=N
     d.bias, d.act = None, ACT_NONE
     d.dact_aux, d.dact, d.addend, d.pool = P(dact_aux), dact, P(addend), int(pool)
     d.tile = tile
+    _weights_for(spec, d, True)
     with _Timed("dgrad", 2.0 * B * Hd * Wd * spec.cout * n_count * spec.kh * spec.kw,
                 "M=%d N=%d K=%dx%d s%d mode%d pool%d %dx%d" % (B * Hs * Ws, n_count, Cout, spec.kh * spec.kw, spec.stride, d.mode, int(pool), Hs, Ws)):
         L.check(L.lib().mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(dgrad)")
@@ -360,12 +398,18 @@ def _dgrad_upsample_merged(spec, dy, in_shape, c1, dact_aux, dact, addend, tile)
     d = IgemmDesc()
     d.x1, d.x2 = P(dy), None
     d.B, d.Hs, d.Ws, d.C1, d.C2, d.up1 = B, Hd, Wd, Cout, 0, 0
-    d.w = P(spec.packed_upmerge_adj(c1))
     d.kh, d.kw, d.Np, d.Kp = 4, 4, up16(c1), up16(spec.cout)
     d.mode, d.stride, d.sign, d.offset, d.pad_mode = G_DIRECT, 2, 1, -3, PAD_ZERO
     d.y, d.Hd, d.Wd, d.Cd, d.n_begin, d.n_count, d.y_choff = P(tmp), Hl + 2, Wl + 2, c1, 0, c1, 0
     d.bias, d.act = None, ACT_NONE
     d.tile = tile & 0xff
+    d.w = P(spec.packed_upmerge_adj(c1))
+    if spec.mma == MMA_BF16:
+        d.mma, d.w16 = 1, d.w
+        if L.lib().mcav_igemm_uses_bf16(ctypes.byref(d)):
+            d.w16 = P(spec.packed_upmerge_adj(c1, bf16=True))
+        else:
+            d.mma, d.w16 = 0, None
     with _Timed("dgrad", 2.0 * B * Hd * Wd * spec.cout * c1 * 9,
                 "M=%d N=%d K=%dx9 s1 mode2 pool1 (merged 4x4/s2) %dx%d" % (B * Hd * Wd, c1, Cout, Hd, Wd)):
         L.check(L.lib().mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(dgrad, merged upsample)")
@@ -390,6 +434,9 @@ def conv_wgrad(spec, x1, dy, x2=None, up1=False, tile=0):
     d.Cout, d.Cin = spec.cout, spec.cin
     d.dw_oihw, d.accumulate, d.dbias = P(gw), 1, P(gb)
     d.tile = tile
+    d.mma = 1 if spec.mma == MMA_BF16 else 0
+    if d.mma and L.lib().mcav_wgrad_uses_bf16(ctypes.byref(d)):
+        tile |= 1 << 11                                   # bf16: one two-source launch (no merged-tap split; the kernel is memory-bound)
     flops = 2.0 * B * dy.shape[1] * dy.shape[2] * spec.cout * spec.cin * spec.kh * spec.kw
     tag = "pix=%d Cout=%d Ktot=%dx%d s%d" % (B * dy.shape[1] * dy.shape[2], spec.cout, spec.cin, spec.kh * spec.kw, spec.stride)
     c1 = x1.shape[3]

@@ -217,11 +217,14 @@ class _DispResNetPairFn(torch.autograd.Function):
 
 
 class DispResNet(nn.Module):
-    def __init__(self, num_layers=18):
-        """The reference hard-codes ResNet-18 (resnet_dispnet.py:101); num_layers=50 is BASELINE.json's configs[3] extension."""
+    def __init__(self, num_layers=18, dtype=None):
+        """The reference hard-codes ResNet-18 (resnet_dispnet.py:101); num_layers=50 is BASELINE.json's configs[3] extension.
+        dtype=torch.bfloat16 opts into the bf16 MFMA conv tiles of configs[2] / [4] (mcav.nn.set_compute_dtype); default fp32 as the reference."""
         super().__init__()
         self.encoder = ResnetEncoder(num_layers, True)
         self.decoder = DepthDecoder(self.encoder.num_ch_enc)
+        if dtype is not None:
+            N.set_compute_dtype(self, dtype)
 
     def forward(self, x):
         return [_DispResNetFn.apply(x, self, *self.parameters())]

@@ -45,6 +45,9 @@ class PoseNet(nn.Module):
             setattr(self, "conv%d" % (i + 1), conv_gn(cin, c, k))
             cin = c
         self.pose_pred = ConvParams(cin, 6 * nb_ref_imgs, 1)
+        if kwargs.get("dtype") is not None:          # opt-in bf16 MFMA tiles (mcav.nn.set_compute_dtype); default fp32 as the reference
+            from mcav import nn as N
+            N.set_compute_dtype(self, kwargs["dtype"])
 
     def init_weights(self):
         for m in self.modules():
