@@ -1,0 +1,213 @@
+"""GPU: the bf16 MFMA conv tiles (csrc/conv_bf16.hip; BASELINE.json configs[2] / [4]).
+
+Kernel parity: the bf16 kernels round the source pixels and the filters to bf16 (round-to-nearest-even) and accumulate in fp32, so against a
+float64 torch reference evaluated on the SAME rounded operands they must agree to fp32 accumulation error -- an exact statement, not a
+"bf16 tolerance".  Network accuracy: the depth maps of the bf16 depth net against the fp32 CPU oracle, with the measured numbers asserted
+(the north_star's 1e-3 bound is a statement about the fp32 path; SURVEY.md section 7 (v): bf16 configs need an accuracy statement of their own).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from seeding import reinit_by_name
+from test_conv_gpu import nchw, nhwc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def r16(t):
+    return t.detach().to(torch.bfloat16).to(torch.float64)
+
+
+def bf16_spec(w, b, stride, pad, pad_mode):
+    from mcav import nn as N
+    spec = N.ConvSpec(torch.nn.Parameter(w.detach().to(DEV)), None if b is None else torch.nn.Parameter(b.detach().to(DEV)), stride, pad, pad_mode)
+    spec.mma = N.MMA_BF16
+    return spec
+
+
+def ref_conv64(x, w, b, stride, pad, pad_mode):
+    x, w = x.double(), w.double()
+    if pad_mode == 1 and pad > 0:
+        x = F.pad(x, (pad,) * 4, mode="reflect")
+        pad = 0
+    return F.conv2d(x, w, None if b is None else b.double(), stride=stride, padding=pad)
+
+
+CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, pad_mode     (what the launch exercises)
+    (2, 12, 20, 64, 64, 3, 1, 1, 0),       # 64x64 tiles, 64-deep K-tiles, zero padding (ResNet 3x3)
+    (2, 12, 20, 32, 64, 3, 1, 1, 0),       # 32-deep K-tiles (Kp % 64 != 0)
+    (1, 10, 18, 64, 128, 3, 2, 1, 0),      # stride 2, and its parity-class adjoint
+    (2, 9, 15, 64, 128, 1, 2, 0, 0),       # 1x1 stride-2 downsample, odd sizes
+    (2, 12, 20, 128, 64, 3, 1, 1, 1),      # reflection padding (decoder), reflect-adjoint data gradient with border wavefronts
+    (2, 6, 10, 96, 32, 3, 1, 1, 1),        # Cin = 96 (32-deep), 32 output channels
+    (3, 6, 20, 512, 512, 3, 1, 1, 0),      # few rows: 32x64 tiles on the 16x16x32 MFMA
+    (6, 48, 160, 64, 64, 3, 1, 1, 0),      # many rows: 128x64 tiles
+    (2, 5, 7, 256, 128, 3, 1, 1, 1),       # ragged rows, reflection, deep K
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_bf16_conv_fwd_dgrad_wgrad_vs_rounded_operands(case):
+    from mcav import nn as N
+    B, H, W, Cin, Cout, k, stride, pad, pad_mode = case
+    g = torch.Generator().manual_seed(abs(hash(case)) % 10000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    b = 0.1 * torch.randn(Cout, generator=g)
+    spec = bf16_spec(w, b, stride, pad, pad_mode)
+    xin = nhwc(x)
+    # forward: y = conv(round(x), round(w)) + b in fp32 accumulation
+    got = N.conv_fwd(spec, xin)
+    assert "f16" in spec._packs, "the forward launch did not take the bf16 kernel"
+    want = ref_conv64(r16(x), r16(w), b, stride, pad, pad_mode)
+    assert rel_err(nchw(got), want) < 2e-5
+    # the bf16 result is a real bf16 result: it differs from the fp32 one at the 1e-3..1e-2 level
+    exact = ref_conv64(x, w, b, stride, pad, pad_mode)
+    assert 1e-4 < rel_err(nchw(got), exact) < 3e-2
+    # data gradient: dx = conv_transpose(round(dy), round(w)); reflection padding folds border sources BEFORE the rounding
+    dy = torch.randn(want.shape, generator=g)
+    xr = r16(x).requires_grad_()
+    wr = r16(w).requires_grad_()
+    ref_conv64(xr, wr, None, stride, pad, pad_mode).backward(r16(dy))
+    dx = N.conv_dgrad(spec, nhwc(dy), (H, W))
+    assert "b16" in spec._packs, "the data-gradient launch did not take the bf16 kernel"
+    if pad_mode == 1:
+        inner = (slice(None), slice(None), slice(2, H - 2), slice(2, W - 2))
+        assert rel_err(nchw(dx)[inner], xr.grad[inner]) < 2e-5
+        assert rel_err(nchw(dx), xr.grad) < 1e-2          # border pixels: sum of up to four sources, rounded once
+    else:
+        assert rel_err(nchw(dx), xr.grad) < 2e-5
+    # weight gradient: sum over pixels of round(x) * round(dy), fp32 accumulation, fp32 slab reduction
+    N.conv_wgrad(spec, xin, nhwc(dy))
+    xr2 = r16(x)
+    wq = w.double().clone().requires_grad_()
+    ref_conv64(xr2, wq, None, stride, pad, pad_mode).backward(r16(dy))
+    assert rel_err(spec.weight.grad, wq.grad) < 5e-5
+    assert rel_err(spec.bias.grad, dy.double().sum((0, 2, 3))) < 5e-5      # the bias gradient sums the unrounded dy
+    N.conv_wgrad(spec, xin, nhwc(dy))                   # accumulates
+    assert rel_err(spec.weight.grad, 2 * wq.grad) < 5e-5
+
+
+@pytest.mark.parametrize("B,H,W", [(4, 10, 14), (12, 48, 160)])
+def test_bf16_batchnorm_statistics_epilogue_and_groups(B, H, W):
+    """The BatchNorm column sums come from the fp32 accumulators of the bf16 kernel; two stacked passes keep their statistics apart.
+    The large case is one where the fp32 planner and the bf16 kernels choose DIFFERENT tile heights: the statistics slab must be sized by
+    the kernel that runs (mcav_igemm_mtiles), or the epilogue writes past it."""
+    from mcav import nn as N
+    g = torch.Generator().manual_seed(5)
+    C = 64
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.05
+    spec = bf16_spec(w, None, 1, 1, 0)
+    y, slab = N.conv_fwd(spec, nhwc(x), stats=True, groups=2)
+    want = ref_conv64(r16(x), r16(w), None, 1, 1, 0)
+    assert rel_err(nchw(y), want) < 2e-5
+    mt = slab.shape[0] // 2
+    assert mt == -(-(B // 2 * H * W) // (32 if B * H * W < 32768 else 64)), "slab rows follow the bf16 kernel's tile height"
+    for grp in range(2):
+        s = slab[grp * mt:(grp + 1) * mt].sum(0).cpu()
+        part = want[grp * (B // 2):(grp + 1) * (B // 2)]
+        assert rel_err(s[0], part.sum((0, 2, 3))) < 1e-4
+        assert rel_err(s[1], (part ** 2).sum((0, 2, 3))) < 1e-4
+
+
+def test_bf16_decoder_level_fused_upsample_concat():
+    """conv(cat(up2(a), skip)) with reflection padding on the bf16 kernels: forward, the two-source weight gradient, the skip-half data gradient."""
+    from mcav import nn as N
+    g = torch.Generator().manual_seed(6)
+    B, h, w_, C1, C2, Cout = 2, 6, 10, 64, 64, 64
+    a = torch.randn(B, C1, h, w_, generator=g)
+    skip = torch.randn(B, C2, 2 * h, 2 * w_, generator=g)
+    wt = torch.randn(Cout, C1 + C2, 3, 3, generator=g) * 0.05
+    bs = 0.1 * torch.randn(Cout, generator=g)
+    spec = bf16_spec(wt, bs, 1, 1, 1)
+    ar, sr, wr = r16(a).requires_grad_(), r16(skip).requires_grad_(), r16(wt).requires_grad_()
+    xcat = torch.cat([F.interpolate(ar, scale_factor=2, mode="nearest"), sr], 1)
+    pre = F.conv2d(F.pad(xcat, (1, 1, 1, 1), mode="reflect"), wr, bs.double())
+    dy = torch.randn(pre.shape, generator=g)
+    pre.backward(r16(dy))
+    got = N.conv_fwd(spec, nhwc(a), nhwc(skip), up1=True, act=N.ACT_ELU)
+    assert rel_err(nchw(got), F.elu(pre)) < 2e-5
+    N.conv_wgrad(spec, nhwc(a), nhwc(dy), x2=nhwc(skip), up1=True)
+    assert rel_err(spec.weight.grad, wr.grad) < 5e-5
+    dskip = N.conv_dgrad(spec, nhwc(dy), (2 * h, 2 * w_), n_begin=C1, n_count=C2)
+    inner = (slice(None), slice(None), slice(2, 2 * h - 2), slice(2, 2 * w_ - 2))
+    assert rel_err(nchw(dskip)[inner], sr.grad[inner]) < 2e-5
+
+
+def depth_of(disp):
+    return 1 / (10 * disp.detach().cpu().double() + 0.01)
+
+
+@pytest.mark.parametrize("B,H,W,bound_max,bound_abs", [(2, 64, 128, 0.25, 0.03), (4, 192, 640, 0.25, 0.03)])
+def test_bf16_depth_net_accuracy_statement(B, H, W, bound_max, bound_abs):
+    """The accuracy statement of the bf16 configs: depth maps of the bf16 depth net (random init, train-mode BatchNorm) against the fp32 CPU
+    oracle on identical inputs and weights.  bf16 operands carry 8 significant bits (2^-9 = 2e-3 per product) through ~20 conv layers, so the
+    fp32 path's 1e-3 max-relative bound is out of reach by construction; measured on MI355X and asserted with margin here."""
+    from models.depth.resnet_dispnet import DispResNet
+    from oracle import nets as on
+    hip = reinit_by_name(DispResNet(dtype=torch.bfloat16), 141)
+    ref = on.DispResNet()
+    ref.load_state_dict(hip.state_dict())
+    hip.to(DEV).train()
+    ref.train()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 3, H, W, generator=g)
+    x = F.avg_pool2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), 3, 1)
+    if B * H * W <= 2 * 64 * 128:
+        want = ref(x)[0]
+    else:
+        with torch.no_grad():
+            want = ref(x)[0]
+    got = hip(x.to(DEV))[0]
+    dg, dw = depth_of(got), depth_of(want)
+    rel = (dg - dw).abs() / dw
+    print("bf16 depth net %dx%dx%d: depth AbsRel %.3e, max-rel %.3e, disparity max-abs %.3e" %
+          (B, H, W, float(rel.mean()), float(rel.max()), float((got.detach().cpu() - want.detach()).abs().max())))
+    assert float(rel.mean()) < bound_abs and float(rel.max()) < bound_max
+    # and it is the bf16 path that ran: the same net in fp32 is 100x closer
+    from mcav import nn as N
+    N.set_compute_dtype(hip, torch.float32)
+    rel32 = (depth_of(hip(x.to(DEV))[0]) - dw).abs() / dw
+    assert float(rel32.max()) < 1e-3 and float(rel32.mean()) * 20 < float(rel.mean())
+
+
+def test_bf16_train_step_runs_and_tracks_fp32():
+    """One whole training step with the bf16 depth net: finite, losses within a few per cent of the fp32 step, gradients correlated with the
+    fp32 ones (measured cosines 0.96 .. 0.996 at random init: the rounding noise of 8-bit mantissas through train-mode BatchNorm), and
+    bit-reproducible."""
+    from losses import Losses
+    from mcav.optim import FusedAdam
+    from models.depth.resnet_dispnet import DispResNet
+    from models.pose.pose_net import PoseNet
+    from oracle.step import synthetic_batch
+    s = synthetic_batch(4, 96, 320, seed=9)
+    tgt, refs, K = s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], s["intrinsics"].to(DEV)
+    out = {}
+    for name, dt in (("fp32", None), ("bf16", torch.bfloat16), ("bf16_again", torch.bfloat16)):
+        d = reinit_by_name(DispResNet(dtype=dt), 141).to(DEV).train()
+        p = reinit_by_name(PoseNet(), 121).to(DEV).train()
+        with torch.no_grad():
+            p.pose_pred.weight.mul_(0.1)
+            p.pose_pred.bias.mul_(0.1)
+        opt = FusedAdam(list(d.parameters()) + list(p.parameters()), 1e-4)
+        opt.zero_grad()
+        disps = list(d.forward_pair(tgt, refs[0]))
+        loss = Losses().forward(tgt, refs, disps, p(tgt, refs), K, None)
+        sum(loss).backward()
+        torch.cuda.synchronize()
+        out[name] = ([float(l.detach()) for l in loss], opt.arena().gflat.clone(), dict((n, q.grad.clone()) for n, q in d.named_parameters() if q.grad is not None))
+    (l32, g32, n32), (l16, g16, n16), (l16b, g16b, _) = out["fp32"], out["bf16"], out["bf16_again"]
+    assert l16 == l16b and torch.equal(g16, g16b)
+    assert torch.isfinite(g16).all()
+    for a, b in zip(l16, l32):
+        assert abs(a - b) < 5e-2 * abs(b), (l16, l32)
+    for n in ("encoder.encoder.layer4.1.conv2.weight", "encoder.encoder.layer2.0.conv1.weight", "decoder.decoder.0.conv.conv.weight",
+              "decoder.decoder.5.conv.conv.weight"):
+        cos = float(F.cosine_similarity(n16[n].flatten(), n32[n].flatten(), dim=0))
+        print("bf16 vs fp32 gradient cosine %-45s %.4f" % (n, cos))
+        assert cos > 0.9, (n, cos)

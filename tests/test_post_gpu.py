@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, REPO
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -101,3 +101,45 @@ def test_image_preprocess_vs_pillow_golden():
     got = GpuImageTransform(192, 640)(torch.from_numpy(big))
     for b in range(3):
         assert np.array_equal(got[b].cpu().numpy(), op.load_transform(big[b], 192, 640))
+
+
+def test_prefetch_loader_on_kitti_files_equals_the_reference_chain(tmp_path):
+    """8f row 1, second half: split file -> PIL decode -> pinned copy -> GPU resize + normalise, one batch ahead.  Every frame of every batch
+    equals the reference's transform chain (oracle.preprocess, pinned bit for bit to Pillow) although the two drives differ in image size."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from PIL import Image
+    from kitti_tree import config_for, make_tree
+    from dataloaders import PrefetchLoader, UnSupKittiDataset, raw_collate
+    from oracle import preprocess as op
+    split, rows = make_tree(str(tmp_path))
+    H, W = 24, 80
+    ds = UnSupKittiDataset(config_for(split, str(tmp_path), H, W))
+    order = [0, 3, 1, 4, 2, 5]                       # every batch mixes the two source sizes
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, sampler=order, num_workers=2, drop_last=True, collate_fn=raw_collate)
+    seen = 0
+    for bi, batch in enumerate(PrefetchLoader(loader, H, W, DEV)):
+        assert tuple(batch["tgt"].shape) == (2, 3, H, W) and batch["intrinsics"].dtype == torch.float64 and batch["groundtruth"].is_cuda
+        for j in range(2):
+            r = rows[order[2 * bi + j]]
+            for got, path in ((batch["tgt"][j], r[0]), (batch["ref_imgs"][0][j], r[1]), (batch["ref_imgs"][1][j], r[2])):
+                want = op.load_transform(np.asarray(Image.open(path)), H, W)
+                assert np.array_equal(got.cpu().numpy(), want)
+            seen += 1
+    assert seen == 6
+
+
+def test_trainer_runs_an_epoch_on_kitti_files(tmp_path):
+    """Trainer(config) with datasets.dataset: ['KITTI'] (the reference's configs) starts and trains from a split file."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from kitti_tree import config_for, make_tree
+    from trainer import Trainer
+    split, _ = make_tree(str(tmp_path), frames=8)
+    cfg = config_for(split, str(tmp_path), 64, 128, batch=2)
+    cfg["action"]["num_workers"] = 2
+    t = Trainer(cfg)
+    t.train()
+    assert t.step >= 3 and torch.isfinite(sum(t.loss)).item()
+    acc = t.validate()
+    assert acc is not None and acc["count"] > 0

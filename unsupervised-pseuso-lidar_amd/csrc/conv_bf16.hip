@@ -311,7 +311,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradParams p) {
     __shared__ unsigned s_tab[WG_TABCAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per_split = p.mtiles * p.ntiles;
-    const int split = blockIdx.x / per_split, rem = blockIdx.x - split * per_split;
+    // all row / column tiles of one pixel split read the same pixels (each tap a shifted view of x, every tile the same dy): consecutive
+    // logical ids share an XCD, so the split's pixels are fetched into ONE L2 and re-read from there (the hardware deals workgroups
+    // round-robin over the 8 XCDs; unlike the MFMA-bound fp32 kernel this one is bound by exactly that traffic)
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lid / per_split, rem = lid - split * per_split;
     const int nt = rem % p.ntiles, mt = rem / p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const GatherSrc& g = p.g;
@@ -518,6 +522,7 @@ static int bf16_tile_for(const mcav_igemm_desc* d, bool* refl) {
     if (d->kh * d->kw > TAB_TAPS || d->Kp % 32 != 0 || d->C1 + d->C2 != d->Kp) return 0;
     if ((d->C1 & 3) || (d->C2 & 3) || (d->C2 > 0 && d->C1 % 32 != 0)) return 0;
     if (d->n_count < 32) return 0;                                    // narrow outputs: the halo / stencil kernels
+    if (d->C2 == 0 && d->C1 <= 32 && d->n_count <= 32 && d->kh == 3 && d->stride == 1) return 0;      // conv_halo.hip's shapes (mcav_try_halo runs first)
     const bool direct = d->mode == MCAV_G_DIRECT || (d->mode == MCAV_G_ADJ_STRIDE2 && d->C2 == 0);
     const bool radj = d->mode == MCAV_G_ADJ_REFLECT && d->C2 == 0;
     if (!direct && !radj) return 0;
@@ -545,16 +550,32 @@ int mcav_bf16_igemm(const mcav_igemm_desc* d, hipStream_t s) {
     dd.w_upmerge = nullptr;
     IgemmParams p;
     int tile;
-    if (!fill_params(&dd, p, tile) || p.upm) return 1;
-    if ((long)d->Np * p.Kstride * 2 >= 0x7fffffffL) return 1;
+    // (past this point the caller may have put the bf16 copy into d->w as well: never fall through to the fp32 kernels)
+    if (!fill_params(&dd, p, tile) || p.upm) return MCAV_E_INVALID;
+    if ((long)d->Np * p.Kstride * 2 >= 0x7fffffffL) return MCAV_E_INVALID;
     const bool k64 = bt & 1;
     switch (tile) {
         case 10: if (k64) launch_igemm_bf16<BT64x64k64>(p, d->w16, refl, s); else launch_igemm_bf16<BT64x64k32>(p, d->w16, refl, s); break;
         case 8: if (k64) launch_igemm_bf16<BT128x64k64>(p, d->w16, refl, s); else launch_igemm_bf16<BT128x64k32>(p, d->w16, refl, s); break;
         case 12: if (k64) launch_igemm_bf16<BT32x64k64>(p, d->w16, refl, s); else launch_igemm_bf16<BT32x64k32>(p, d->w16, refl, s); break;
-        default: return 1;
+        default: return MCAV_E_INVALID;
     }
     return launch_status();
+}
+
+// The M-tile count (rows of the BatchNorm statistics slab) of the bf16 launch, whose tile shape is chosen independently of the fp32
+// planner's: 0 when the descriptor does not run on the bf16 kernels.
+int mcav_bf16_igemm_mtiles(const mcav_igemm_desc* d) {
+    bool refl = false;
+    const int bt = bf16_tile_for(d, &refl);
+    if (!bt) return 0;
+    mcav_igemm_desc dd = *d;
+    dd.tile = bt >> 1;
+    dd.w_upmerge = nullptr;
+    IgemmParams p;
+    int tile;
+    if (!fill_params(&dd, p, tile) || p.upm) return 0;
+    return p.mtiles;
 }
 
 MCAV_EXPORT int mcav_igemm_uses_bf16(const mcav_igemm_desc* d) {

@@ -1665,10 +1665,16 @@ inline void launch_igemm(const IgemmParams& p, hipStream_t s) {
 
 using namespace mcav;
 
+int mcav_bf16_igemm_mtiles(const mcav_igemm_desc* d);             // conv_bf16.hip: 0 = the launch does not run there
+
 MCAV_EXPORT int mcav_igemm_mtiles(const mcav_igemm_desc* d) {
     IgemmParams p;
     int tile;
     if (!fill_params(d, p, tile)) return MCAV_E_INVALID;
+    if (d->mma == 1) {                                             // the bf16 kernels choose their own tile shape
+        const int mt = mcav_bf16_igemm_mtiles(d);
+        if (mt > 0) return mt;
+    }
     return p.mtiles;
 }
 

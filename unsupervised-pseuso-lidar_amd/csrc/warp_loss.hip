@@ -91,12 +91,41 @@ template <int N>
 __device__ __forceinline__ void block_reduce_store(float* acc, float* dst, float (*sred)[SLAB]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const float v = wave_sum(acc[k]);
-        if (lane == 0) sred[wave][k] = v;
+    for (int k = 0; k < N; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0) {                          // one exec-masked region for the N stores (not one per value)
+#pragma unroll
+        for (int k = 0; k < N; ++k) sred[wave][k] = acc[k];
     }
     __syncthreads();
     if (threadIdx.x < N) dst[threadIdx.x] = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+}
+
+// Branch-free bilinear gathers: an image (3 planes) is a raw buffer resource, a tap outside the image carries an out-of-range offset and
+// reads as zero in hardware.  No exec-mask branch and no value merge sits between a load and its use, so the 36 gathers of a pixel's three
+// warps are issued back to back behind one counted wait (the predicated form compiled to ~90 exec-masked regions, each with its own wait).
+constexpr unsigned WL_OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const float* img, size_t plane) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, (unsigned)(3 * plane * sizeof(float)), 0x00020000);
+}
+
+struct TapOff { unsigned o[4]; };
+
+__device__ __forceinline__ TapOff tap_offsets(const Tap& t, int W) {
+    const int base = (t.y0 * W + t.x0) * 4;
+    TapOff f;
+    f.o[0] = t.in00 ? (unsigned)base : WL_OOB;
+    f.o[1] = t.in01 ? (unsigned)(base + 4) : WL_OOB;
+    f.o[2] = t.in10 ? (unsigned)(base + W * 4) : WL_OOB;
+    f.o[3] = t.in11 ? (unsigned)(base + W * 4 + 4) : WL_OOB;
+    return f;
+}
+
+__device__ __forceinline__ void gather_taps(__amdgpu_buffer_rsrc_t rs, const TapOff& f, int plane_bytes, float (*q)[4]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)f.o[k], c * plane_bytes, 0));
 }
 
 __global__ __launch_bounds__(256) void warp_loss_kernel(WLArgs a) {
@@ -127,42 +156,66 @@ __global__ __launch_bounds__(256) void warp_loss_kernel(WLArgs a) {
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
 
+    const PrepConst& pc = a.pc[b];
+    const float* tgt = a.tgt + (size_t)b * 3 * plane;
+    const float* ref0 = a.ref0 + (size_t)b * 3 * plane;
+    const float* ref1 = a.ref1 + (size_t)b * 3 * plane;
+    const int pb = (int)(plane * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_t = image_rsrc(tgt, plane), rs_r0 = image_rsrc(ref0, plane), rs_r1 = image_rsrc(ref1, plane);
+    const __amdgpu_buffer_rsrc_t rs_dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.disp_r0 + (size_t)b * plane), 0, (unsigned)pb, 0x00020000);
+    const float invN = 1.0f / (float)((size_t)a.B * 3 * plane);
+    const float cxx = 1.0f / (float)((size_t)a.B * H * (W - 2));
+    const float cyy = 1.0f / (float)((size_t)a.B * (H - 2) * W);
+    const float cxy = 2.0f / (float)((size_t)a.B * (H - 1) * (W - 1));   // dxdy and dydx are the same field
+    // the target-aligned values of a pixel (3 tgt, 3 ref1, 1 disparity) are fetched ONE PIXEL AHEAD, branch-free (a pixel outside the image
+    // reads zeros through the out-of-range offset and is skipped), so their flight overlaps the previous pixel's arithmetic
+    auto fetch = [&](int sub, float (&v)[7]) {      // v = tgt[0..2], ref1[0..2], disparity of ref0
+        const int y = by0 + sub * TH + ty0;
+        const unsigned off = (x < W && y < H) ? (unsigned)((y * W + x) * 4) : WL_OOB;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_t, (int)off, c * pb, 0));
+            v[3 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r1, (int)off, c * pb, 0));
+        }
+        v[6] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dr, (int)off, 0, 0));
+    };
+    float pv[WL_SUB][7];
+    fetch(0, pv[0]);
+#pragma unroll
     for (int sub = 0; sub < WL_SUB; ++sub) {
         const int ty = sub * TH + ty0, y = by0 + ty;
-        if (!(x < W && y < H)) continue;
-        const PrepConst& pc = a.pc[b];
-        const size_t pix = (size_t)y * W + x;
-        const float* tgt = a.tgt + (size_t)b * 3 * plane;
-        const float* ref0 = a.ref0 + (size_t)b * 3 * plane;
-        const float* ref1 = a.ref1 + (size_t)b * 3 * plane;
-        const int cy = ty + HALO, cx = tx + HALO;
-        const float Dt = sD[cy][cx];
-        const float vr = a.disp_r0[(size_t)b * plane + pix];
-        const float Dr = in_depth ? vr : 1.0f / (10.0f * vr + 0.01f);
-        float tv[3], rv[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { tv[c] = tgt[c * plane + pix]; rv[c] = ref1[c * plane + pix]; }
-        const Ray r = pixel_ray(pc.sc.Kinv, (float)x, (float)y);
-        const float invN = 1.0f / (float)((size_t)a.B * 3 * plane);
-        float dDt = 0.f, dDr = 0.f;
-        // warp 0: ref0 -> tgt view, depth(tgt), pose[0]
-        warp_pixel(ref0, plane, tv, pc.sc.w[0].P, r, Dt, H, W, a.tw[0] * invN, g0 * a.tw[0] * invN, acc[0], dDt, acc + 2);
-        // warp 1: ref1 -> tgt view, depth(tgt), pose[1]
-        warp_pixel(ref1, plane, tv, pc.sc.w[1].P, r, Dt, H, W, a.tw[1] * invN, g0 * a.tw[1] * invN, acc[0], dDt, acc + 14);
-        // warp 2: tgt -> "ref1 view", depth(ref0), inverse(pose[0])   (reference quirk, losses.py:203-207)
-        warp_pixel(tgt, plane, rv, pc.sc.w[2].P, r, Dr, H, W, a.tw[2] * invN, g0 * a.tw[2] * invN, acc[0], dDr, acc + 26);
-
-        if (!(a.flags & MCAV_WL_NO_SMOOTH)) {
-            const float cxx = 1.0f / (float)((size_t)a.B * H * (W - 2));
-            const float cyy = 1.0f / (float)((size_t)a.B * (H - 2) * W);
-            const float cxy = 2.0f / (float)((size_t)a.B * (H - 1) * (W - 1));   // dxdy and dydx are the same field
-            float gs = 0.f, ls = 0.f;
-            smooth_terms([&](int dy, int dx) { return sD[cy + dy][cx + dx]; }, x, y, H, W, cxx, cyy, cxy, ls, gs);
-            acc[1] += ls;
-            dDt += g1 * gs;
+        if (sub + 1 < WL_SUB) fetch(sub + 1, pv[sub + 1]);
+        const float tvv[3] = {pv[sub][0], pv[sub][1], pv[sub][2]}, rvv[3] = {pv[sub][3], pv[sub][4], pv[sub][5]};
+        const float vr = pv[sub][6];
+        if (x < W && y < H) {
+            const size_t pix = (size_t)y * W + x;
+            const int cy = ty + HALO, cx = tx + HALO;
+            const float Dt = sD[cy][cx];
+            const float Dr = in_depth ? vr : 1.0f / (10.0f * vr + 0.01f);
+            const Ray r = pixel_ray(pc.sc.Kinv, (float)x, (float)y);
+            float dDt = 0.f, dDr = 0.f;
+            // the three projections first, then all 36 gathers, then the arithmetic (same operations in the same order as warp_pixel)
+            // warp 0: ref0 -> tgt view, depth(tgt), pose[0];  warp 1: ref1 -> tgt view, depth(tgt), pose[1];
+            // warp 2: tgt -> "ref1 view", depth(ref0), inverse(pose[0])   (reference quirk, losses.py:203-207)
+            const Tap t0 = project_pixel(pc.sc.w[0].P, r, Dt, H, W);
+            const Tap t1 = project_pixel(pc.sc.w[1].P, r, Dt, H, W);
+            const Tap t2 = project_pixel(pc.sc.w[2].P, r, Dr, H, W);
+            float q0[3][4], q1[3][4], q2[3][4];
+            gather_taps(rs_r0, tap_offsets(t0, W), pb, q0);
+            gather_taps(rs_r1, tap_offsets(t1, W), pb, q1);
+            gather_taps(rs_t, tap_offsets(t2, W), pb, q2);
+            warp_pixel_from(q0, tvv, pc.sc.w[0].P, r, t0, H, W, a.tw[0] * invN, g0 * a.tw[0] * invN, acc[0], dDt, acc + 2);
+            warp_pixel_from(q1, tvv, pc.sc.w[1].P, r, t1, H, W, a.tw[1] * invN, g0 * a.tw[1] * invN, acc[0], dDt, acc + 14);
+            warp_pixel_from(q2, rvv, pc.sc.w[2].P, r, t2, H, W, a.tw[2] * invN, g0 * a.tw[2] * invN, acc[0], dDr, acc + 26);
+            if (!(a.flags & MCAV_WL_NO_SMOOTH)) {
+                float gs = 0.f, ls = 0.f;
+                smooth_terms_sel([&](int dy, int dx) { return sD[cy + dy][cx + dx]; }, x, y, H, W, cxx, cyy, cxy, ls, gs);
+                acc[1] += ls;
+                dDt += g1 * gs;
+            }
+            a.d_disp_t[(size_t)b * plane + pix] = in_depth ? dDt : dDt * (-10.0f * Dt * Dt);
+            a.d_disp_r0[(size_t)b * plane + pix] = in_depth ? dDr : dDr * (-10.0f * Dr * Dr);
         }
-        a.d_disp_t[(size_t)b * plane + pix] = in_depth ? dDt : dDt * (-10.0f * Dt * Dt);
-        a.d_disp_r0[(size_t)b * plane + pix] = in_depth ? dDr : dDr * (-10.0f * Dr * Dr);
     }
     const int nblk = gridDim.x * gridDim.y;
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;

@@ -133,6 +133,15 @@ MCAV_HD Tap project_pixel(const float* P, const Ray& r, float D, int H, int W) {
 // Bilinear value and its derivative w.r.t. (ix, iy) for one channel plane.
 struct Sample { float v, dvdx, dvdy; };
 
+// the four texels of a tap (zero where the tap lies outside the image) -> value and derivatives
+MCAV_HD Sample bilinear_from(float nw, float ne, float sw, float se, const Tap& t) {
+    Sample s;
+    s.v = nw * (t.wx0 * t.wy0) + ne * (t.wx1 * t.wy0) + sw * (t.wx0 * t.wy1) + se * (t.wx1 * t.wy1);
+    s.dvdx = -nw * t.wy0 + ne * t.wy0 - sw * t.wy1 + se * t.wy1;
+    s.dvdy = -nw * t.wx0 - ne * t.wx1 + sw * t.wx0 + se * t.wx1;
+    return s;
+}
+
 MCAV_HD Sample bilinear(const float* plane, int W, const Tap& t) {
     const float nw = t.in00 ? plane[t.y0 * W + t.x0] : 0.0f;
     const float ne = t.in01 ? plane[t.y0 * W + t.x0 + 1] : 0.0f;
@@ -186,9 +195,42 @@ MCAV_HD void smooth_terms(F DD, int x, int y, int H, int W, float cxx, float cyy
     if (y >= 1 && x >= 1) { const float u = (DD(0, 0) - DD(0, -1)) - (DD(-1, 0) - DD(-1, -1)); gs += sgn(u) * cxy; }
 }
 
+// The same ten terms with every condition turned into a 0 / weight factor (no exec-mask branches in the fused kernel).  DD must be readable
+// at every offset within +-2 (the kernel's tile carries a zero-filled halo of 2), and a masked term adds +-0: bit-identical sums.
+template <class F>
+MCAV_HD void smooth_terms_sel(F DD, int x, int y, int H, int W, float cxx, float cyy, float cxy, float& ls, float& gs) {
+    const float d00 = DD(0, 0);
+    { const float t = DD(0, 2) - 2.f * DD(0, 1) + d00; const float m = x <= W - 3 ? cxx : 0.f; ls += fabsf(t) * m; gs += sgn(t) * m; }
+    { const float t = DD(0, 1) - 2.f * d00 + DD(0, -1); const float m = (x >= 1 && x <= W - 2) ? cxx : 0.f; gs -= 2.f * sgn(t) * m; }
+    { const float t = d00 - 2.f * DD(0, -1) + DD(0, -2); const float m = x >= 2 ? cxx : 0.f; gs += sgn(t) * m; }
+    { const float t = DD(2, 0) - 2.f * DD(1, 0) + d00; const float m = y <= H - 3 ? cyy : 0.f; ls += fabsf(t) * m; gs += sgn(t) * m; }
+    { const float t = DD(1, 0) - 2.f * d00 + DD(-1, 0); const float m = (y >= 1 && y <= H - 2) ? cyy : 0.f; gs -= 2.f * sgn(t) * m; }
+    { const float t = d00 - 2.f * DD(-1, 0) + DD(-2, 0); const float m = y >= 2 ? cyy : 0.f; gs += sgn(t) * m; }
+    { const float u = (DD(1, 1) - DD(1, 0)) - (DD(0, 1) - d00); const float m = (y <= H - 2 && x <= W - 2) ? cxy : 0.f; ls += fabsf(u) * m; gs += sgn(u) * m; }
+    { const float u = (DD(1, 0) - DD(1, -1)) - (d00 - DD(0, -1)); const float m = (y <= H - 2 && x >= 1) ? cxy : 0.f; gs -= sgn(u) * m; }
+    { const float u = (DD(0, 1) - d00) - (DD(-1, 1) - DD(-1, 0)); const float m = (y >= 1 && x <= W - 2) ? cxy : 0.f; gs -= sgn(u) * m; }
+    { const float u = (d00 - DD(0, -1)) - (DD(-1, 0) - DD(-1, -1)); const float m = (y >= 1 && x >= 1) ? cxy : 0.f; gs += sgn(u) * m; }
+}
+
 // One warp at one pixel: photometric L1 over 3 channel planes + gradient back to depth and P.
 // src: 3 planes of the source image (stride `plane`), tv: the 3 target values.
 // lw: weight of |res| in the loss; gw: weight of sign(res) in the gradient (= upstream * lw).
+// The same with the 3 x 4 texels already fetched (q[c][0..3] = nw, ne, sw, se of channel c): the fused kernel issues the gathers of all
+// three warps of a pixel before it consumes any (csrc/warp_loss.hip).
+MCAV_HD void warp_pixel_from(const float (*q)[4], const float* tv, const float* P, const Ray& r, const Tap& t, int H, int W,
+                             float lw, float gw, float& loss, float& dD, float* dP) {
+    float gix = 0.f, giy = 0.f;
+    for (int c = 0; c < 3; ++c) {
+        const Sample s = bilinear_from(q[c][0], q[c][1], q[c][2], q[c][3], t);
+        const float res = s.v - tv[c];
+        loss += fabsf(res) * lw;
+        const float sg = sgn(res) * gw;
+        gix += sg * s.dvdx;
+        giy += sg * s.dvdy;
+    }
+    dD += backproject_grad(P, r, t, gix, giy, H, W, dP);
+}
+
 MCAV_HD void warp_pixel(const float* src, size_t plane, const float* tv, const float* P, const Ray& r, float D, int H, int W,
                         float lw, float gw, float& loss, float& dD, float* dP) {
     const Tap t = project_pixel(P, r, D, H, W);

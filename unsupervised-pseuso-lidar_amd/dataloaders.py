@@ -1,8 +1,9 @@
 """dataloaders.py -- sample source for the trainer.
 
-The reference's KITTI loader (dataloaders.py:14-252) is PIL decode + a torchvision transform chain + calib/oxts parsing.  KITTI
-is not available offline, so the file-walking part is not built; the transform chain -- the part with arithmetic in it -- is
-(GpuImageTransform: SURVEY.md section 8f "next" row 1).  What the
+The reference's KITTI loader (dataloaders.py:14-252) is PIL decode + a torchvision transform chain + calib/oxts parsing.  Built here:
+the split-file driven reader (UnSupKittiFiles: paths, P_rect_02 intrinsics, ground-truth maps; tested on a generated KITTI-shaped
+tree, KITTI itself is not available offline), the transform chain on the GPU (GpuImageTransform: SURVEY.md section 8f "next" row 1) and
+the one-batch-ahead PrefetchLoader that joins them.  Not built: the OXTS pose packets of the semi-supervised experiment.  What the
 training step consumes is kept: a dict with 'tgt' [3,H,W], 'ref_imgs' [2 x [3,H,W]], 'intrinsics' [3,3] fp64,
 'groundtruth' [1,H,W] (reference dataloaders.py:226-251).  SyntheticTriplets produces such samples from a seed.
 """
@@ -122,8 +123,213 @@ def synthetic_batch(B, H, W, seed=1234):
     return {"tgt": imgs[0], "ref_imgs": [imgs[1], imgs[2]], "intrinsics": K, "groundtruth": torch.zeros(B, 1, H, W)}
 
 
+# ------------------------------------------------------------------------------------------------ KITTI files (reference dataloaders.py:18-171)
+def read_calib_file(path):
+    """'key: v0 v1 ...' lines -> {key: float64 array}; non-numeric values (dates) are skipped (reference geometry/calibration.py:70-89)."""
+    data = {}
+    with open(path, "r") as f:
+        for line in f:
+            line = line.rstrip()
+            if not line or ":" not in line:
+                continue
+            key, value = line.split(":", 1)
+            try:
+                data[key] = np.array([float(x) for x in value.split()])
+            except ValueError:
+                pass
+    return data
+
+
+def find_calib_dir(image_path):
+    """The KITTI date directory (.../2011_09_26/) above an image path.  The reference slices a fixed number of characters off the path
+    (dataloaders.py:155: [:29], 'mac - 20, beauty - 29'), which only works for its two directory layouts."""
+    import os
+    import re
+    d = os.path.dirname(os.path.abspath(image_path)) if os.path.isabs(image_path) else os.path.dirname(image_path)
+    while d and d not in ("/", "."):
+        if re.fullmatch(r"\d{4}_\d{2}_\d{2}", os.path.basename(d)):
+            return d + os.sep
+        d = os.path.dirname(d)
+    raise FileNotFoundError("no KITTI date directory (YYYY_MM_DD) above %s" % image_path)
+
+
+class KittiDataset(Dataset):
+    """Reference dataloaders.py:18-128.  Samples hold file paths only; an image is decoded on fetch (PIL, on the host).
+
+    Two ways to get the reference's tensors out of it:
+      * `transforms` = a list of host callables applied exactly as load_img does (all but the last to every image, the last -- Normalize --
+        not to the ground truth): the reference's own contract, for callers that bring torchvision;
+      * `transforms=None` (what Trainer passes): fetches return the decoded uint8 image ('raw' samples) and the transform chain
+        (/255, Resize, Normalize) runs on the GPU in PrefetchLoader / GpuImageTransform, bit-exact against Pillow.
+    OXTS poses ('oxts', used only by the reference's semi-supervised pose experiment, trainer.py:301-304) are not loaded."""
+
+    def __init__(self, config, transforms=None):
+        super().__init__()
+        ds = config['datasets']
+        self.split = ds['split']
+        self.kitti_filepath = ds['path']
+        self.img_width = ds['augmentation']['image_width']
+        self.img_height = ds['augmentation']['image_height']
+        self.seq_len = ds.get('sequence_length', 3)
+        self.transforms = transforms
+        self.raw = transforms is None
+        self.samples = []
+        self._calib = {}
+
+    def __len__(self):
+        return len(self.samples)
+
+    def resolve(self, path):
+        """Split-file paths are relative to the directory the reference is run from; also accept them relative to datasets.path."""
+        import os
+        if os.path.exists(path):
+            return path
+        tail = path.lstrip("./")
+        for root in (self.kitti_filepath, os.path.dirname(os.path.normpath(self.kitti_filepath))):
+            for cand in (os.path.join(root, tail), os.path.join(root, *tail.split("/")[1:]) if "/" in tail else None):
+                if cand and os.path.exists(cand):
+                    return cand
+        return path
+
+    def intrinsics_of(self, image_path):
+        """calib.P[:, :3] of the drive's date directory (reference dataloaders.py:155-157), cached per directory; a fresh copy per call."""
+        d = find_calib_dir(self.resolve(image_path))
+        if d not in self._calib:
+            self._calib[d] = read_calib_file(d + "calib_cam_to_cam.txt")["P_rect_02"].reshape(3, 4)[:, :3].copy()
+        return self._calib[d].copy()
+
+    def load_img(self, path, gt=False):
+        """-> (image, original height, original width).  raw mode: uint8 [H0, W0, 3] tensor (the GPU runs the chain); ground truth: the
+        depth PNG as float32, resized with Pillow's bilinear filter on mode 'F' (what ToPILImage + Resize do to a float map), [1, h, w]."""
+        from PIL import Image
+        img = Image.open(self.resolve(path))
+        if gt:
+            arr = np.asarray(img, dtype=np.float32)
+            if self.transforms is not None:
+                for t in self.transforms[:-1]:
+                    arr = t(arr)
+                return arr.squeeze(), None, None
+            small = Image.fromarray(arr, mode="F").resize((self.img_width, self.img_height), Image.BILINEAR)
+            return torch.from_numpy(np.asarray(small, dtype=np.float32).copy())[None], None, None
+        arr = np.asarray(img.convert("RGB") if img.mode != "RGB" else img)
+        h, w = arr.shape[0], arr.shape[1]
+        if self.transforms is not None:
+            x = arr.astype(np.float32) / 255.0
+            for t in self.transforms[:-1]:
+                x = t(x)
+            return self.transforms[-1](x).squeeze(), h, w
+        return torch.from_numpy(arr.copy()), h, w
+
+    def __getitem__(self, index):
+        sample = self.samples[index]
+        ret = {}
+        ret['tgt'], og_h, og_w = self.load_img(sample['tgt'])
+        ret['ref_imgs'] = [self.load_img(p)[0] for p in sample['ref_imgs']]
+        K = sample['intrinsics'].copy()                  # the reference scales the CACHED matrix in place on every fetch (dataloaders.py:95-98)
+        K[0] *= self.img_width / og_w
+        K[1] *= self.img_height / og_h
+        ret['intrinsics'] = torch.from_numpy(K)
+        if sample.get('groundtruth'):
+            ret['groundtruth'] = self.load_img(sample['groundtruth'], gt=True)[0]
+        else:
+            ret['groundtruth'] = torch.zeros(1, self.img_height, self.img_width)
+        return ret
+
+
+class UnSupKittiFiles(KittiDataset):
+    """Reference UnSupKittiDataset (dataloaders.py:131-171): one sample per line of the split file,
+    '<tgt.png> <ref0.png> <ref1.png> <groundtruth.png>'."""
+
+    def __init__(self, config, transforms=None):
+        super().__init__(config, transforms)
+        with open(self.split, "r") as f:
+            lines = [ln.strip() for ln in f if ln.strip()]
+        for ln in lines:
+            parts = ln.split(" ")
+            if len(parts) < 3:
+                raise ValueError("split file %s: expected 'tgt ref0 ref1 [groundtruth]', got %r" % (self.split, ln))
+            self.samples.append({'tgt': parts[0], 'ref_imgs': parts[1:3], 'intrinsics': self.intrinsics_of(parts[0]),
+                                 'groundtruth': parts[3] if len(parts) > 3 else None})
+
+
+def raw_collate(samples):
+    """collate_fn for raw samples: KITTI drives differ in image size (375x1242, 370x1226, ...), so the uint8 images cannot be stacked on
+    the host; the list goes to PrefetchLoader, which resizes on the GPU."""
+    return samples
+
+
+class PrefetchLoader:
+    """One batch ahead: a background thread takes the DataLoader's raw sample lists, copies the decoded uint8 frames to the GPU through pinned
+    memory on its own stream, runs the fused /255 + Pillow-exact resize + Normalize kernel there (GpuImageTransform, grouped by source size)
+    and hands the trainer finished batches in the reference's collated layout (tgt [B,3,h,w], ref_imgs 2 x [B,3,h,w], intrinsics [B,3,3] fp64,
+    groundtruth [B,1,h,w]) together with the event the consumer's stream has to wait on.  SURVEY.md 8f row 1, second half."""
+
+    def __init__(self, loader, img_height, img_width, device="cuda", depth=2):
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())          # the worker thread needs an explicit index
+        self.loader, self.h, self.w, self.device, self.depth = loader, int(img_height), int(img_width), dev, depth
+        self.transform = GpuImageTransform(img_height, img_width, dev)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _finish(self, samples, stream):
+        B = len(samples)
+        frames = [s['tgt'] for s in samples] + [s['ref_imgs'][0] for s in samples] + [s['ref_imgs'][1] for s in samples]
+        out = torch.empty((3 * B, 3, self.h, self.w), dtype=torch.float32, device=self.device)
+        with torch.cuda.stream(stream):
+            groups = {}
+            for i, f in enumerate(frames):
+                groups.setdefault(tuple(f.shape), []).append(i)
+            for shape, idx in groups.items():
+                out[idx] = self.transform(torch.stack([frames[i] for i in idx]))
+            K = torch.stack([s['intrinsics'] for s in samples]).to(self.device, non_blocking=True)
+            gt = torch.stack([s['groundtruth'] for s in samples]).to(self.device, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(stream)
+        return {'tgt': out[:B], 'ref_imgs': [out[B:2 * B], out[2 * B:]], 'intrinsics': K, 'groundtruth': gt}, done
+
+    def __iter__(self):
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.depth)
+        stream = torch.cuda.Stream(device=self.device)
+        dev = self.device
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                for samples in self.loader:
+                    q.put(self._finish(samples, stream))
+                q.put(None)
+            except BaseException as e:          # surface loader errors in the consumer
+                q.put(e)
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            batch, done = item
+            torch.cuda.current_stream(self.device).wait_event(done)
+            for v in [batch['tgt']] + batch['ref_imgs'] + [batch['intrinsics'], batch['groundtruth']]:
+                v.record_stream(torch.cuda.current_stream(self.device))
+            yield batch
+        t.join()
+
+
 def UnSupKittiDataset(config, transforms=None):
+    """The dataset the trainer asks for (reference trainer.py:106): datasets.dataset == ['synthetic'] -> seeded synthetic triplets (no KITTI
+    offline); anything else -> the split-file driven KITTI reader above.  A missing split file or data root fails HERE, at configuration
+    time, with the path in the message."""
+    import os
     if config['datasets'].get('dataset', ['KITTI']) == ['synthetic']:
         return SyntheticTriplets(config, transforms)
-    raise NotImplementedError("the KITTI file loader is outside this round's hot path (SURVEY.md 8f); set "
-                              "datasets.dataset: ['synthetic'] or pass dataset= to Trainer")
+    split = config['datasets']['split']
+    if not os.path.exists(split):
+        raise FileNotFoundError("datasets.split = %r does not exist (KITTI is not shipped with this repository; set datasets.dataset: "
+                                "['synthetic'] for seeded synthetic triplets, or point datasets.split / datasets.path at a KITTI raw tree)" % split)
+    return UnSupKittiFiles(config, transforms)

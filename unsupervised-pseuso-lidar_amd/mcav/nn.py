@@ -435,12 +435,22 @@ def conv_wgrad(spec, x1, dy, x2=None, up1=False, tile=0):
     d.dw_oihw, d.accumulate, d.dbias = P(gw), 1, P(gb)
     d.tile = tile
     d.mma = 1 if spec.mma == MMA_BF16 else 0
-    if d.mma and L.lib().mcav_wgrad_uses_bf16(ctypes.byref(d)):
-        tile |= 1 << 11                                   # bf16: one two-source launch (no merged-tap split; the kernel is memory-bound)
+    bf16 = bool(d.mma and L.lib().mcav_wgrad_uses_bf16(ctypes.byref(d)))
     flops = 2.0 * B * dy.shape[1] * dy.shape[2] * spec.cout * spec.cin * spec.kh * spec.kw
     tag = "pix=%d Cout=%d Ktot=%dx%d s%d" % (B * dy.shape[1] * dy.shape[2], spec.cout, spec.cin, spec.kh * spec.kw, spec.stride)
     c1 = x1.shape[3]
-    if (up1 and x2 is not None and spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad == 1 and spec.pad_mode == PAD_REFLECT
+    if bf16 and x2 is not None and c1 % 16 == 0 and x2.shape[3] % 16 == 0:
+        # bf16: the two sources as two single-source launches (a two-source row tile would fetch both tensors for every tap: measured 4x slower);
+        # each writes its own input-channel range of the OIHW gradient.  The merged-tap form is not used: the bf16 kernels are memory-bound.
+        c2 = x2.shape[3]
+        d.x1, d.x2, d.C1, d.C2, d.up1, d.Kp = P(x2), None, c2, 0, 0, c2
+        d.Cin, d.Cin_total, d.ci_offset, d.upm = c2, spec.cin, c1, 0
+        launch_wgrad(d, (x2, dy), flops * c2 / spec.cin, tag + " [second source, bf16]")
+        d.x1, d.C1, d.up1, d.Kp = P(x1), c1, int(up1), c1
+        d.Cin, d.ci_offset, d.dbias = c1, 0, None
+        launch_wgrad(d, (x1, dy), flops * c1 / spec.cin, tag + " [first source, bf16]")
+        return
+    if (not bf16 and up1 and x2 is not None and spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad == 1 and spec.pad_mode == PAD_REFLECT
             and c1 % 16 == 0 and x2.shape[3] % 16 == 0 and Hs % 2 == 0 and Ws % 2 == 0 and not (tile >> 11) & 1
             and (spec.cout >= 64 or (tile >> 12) & 1)):       # measured: 32 output channels are faster in one launch (bit 12 forces)
         # two launches: the skip tensor's channels as an ordinary weight gradient, the upsampled map's in merged-tap form (mcav_conv.h)

@@ -125,6 +125,13 @@ class Trainer:
             np.random.shuffle(indices)
         train_indices, val_indices = indices[split:], indices[:split]
         train_indices = mdist.shard_indices(train_indices, self.rank, self.world)      # data parallel: disjoint slices
+        if getattr(self.dataset, "raw", False):
+            # file-backed samples decoded to uint8 on the host (worker processes); resize + normalise on the GPU, one batch ahead
+            from dataloaders import PrefetchLoader, raw_collate
+            mk = lambda idx: PrefetchLoader(torch.utils.data.DataLoader(self.dataset, batch_size=self.batch_size, sampler=SequentialIndicesSampler(idx),
+                                                                        num_workers=self.num_workers, drop_last=True, collate_fn=raw_collate),
+                                            self.dataset.img_height, self.dataset.img_width, self.device)
+            return mk(train_indices), mk(val_indices)
         mk = lambda idx: torch.utils.data.DataLoader(self.dataset, batch_size=self.batch_size, sampler=SequentialIndicesSampler(idx),
                                                      num_workers=self.num_workers, drop_last=True, pin_memory=True)
         return mk(train_indices), mk(val_indices)
