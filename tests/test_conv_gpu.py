@@ -187,6 +187,40 @@ def test_stem_smallc():
     assert rel_err(wp.grad, w.grad) < 5e-5
 
 
+@pytest.mark.parametrize("B,H,W", [(4, 64, 128), (2, 45, 70), (3, 192, 640)])
+def test_stem_patch_kernels_forward_stats_wgrad(B, H, W):
+    """csrc/conv_stem.hip: the 7x7 stride-2 image stem with the input patch in LDS -- forward with the BatchNorm statistics of two stacked
+    passes, and the persistent weight-gradient kernel -- against torch, on whole, ragged and full-size maps; and against the general
+    kernels (desc.tile bit 9) it replaces."""
+    from mcav import nn as N
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).requires_grad_()
+    y = F.conv2d(x, w, None, stride=2, padding=3)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    wp = torch.nn.Parameter(w.detach().to(DEV))
+    spec = N.ConvSpec(wp, None, 2, 3, 0, smallc=True)
+    x4 = N.nchw_to_nhwc(x.to(DEV), 4)
+    groups = 2 if B % 2 == 0 else 1
+    got, slab = N.conv_fwd(spec, x4, stats=True, groups=groups)
+    assert getattr(spec, "_stem", None) is not None, "the stem launch did not take the patch kernel"
+    assert rel_err(nchw(got), y) < 2e-5
+    mt = slab.shape[0] // groups
+    assert mt == (B // groups) * (-(-y.shape[2] // 8)) * (-(-y.shape[3] // 32))
+    for grp in range(groups):
+        s_ = slab[grp * mt:(grp + 1) * mt].sum(0).cpu()
+        part = y.detach()[grp * (B // groups):(grp + 1) * (B // groups)]
+        assert rel_err(s_[0], part.sum((0, 2, 3))) < 1e-4
+        assert rel_err(s_[1], (part ** 2).sum((0, 2, 3))) < 1e-4
+    old = N.conv_fwd(spec, x4, tile=0x200)
+    assert rel_err(got, old) < 2e-5
+    N.conv_wgrad(spec, x4, nhwc(dy))
+    assert rel_err(wp.grad, w.grad) < 5e-5
+    N.conv_wgrad(spec, x4, nhwc(dy))                  # accumulates
+    assert rel_err(wp.grad, 2 * w.grad) < 5e-5
+
+
 def test_batchnorm_train_and_backward():
     from mcav import nn as N
     from mcav.holders import BNParams

@@ -1554,6 +1554,10 @@ inline int pick_tile(const mcav_igemm_desc* d, long M) {
     if (d->tile) return d->tile;
     if (d->n_count <= 16) return M >= 256 * 64 ? 4 : 6;
     if (d->n_count <= 32) return 3;
+    // The reflection-adjoint kind carries three extra register stages for its border loads: on the 128-row tiles that is 122 VGPRs and two
+    // workgroups per CU.  Measured (MI355X, bench.py --layer-report, 96x320 / 48x160 maps): 128x64 0.370 / 0.129 / 0.181 ms, 64x64x32
+    // 0.331 / 0.113 / 0.159, 64x64x16 0.300 / 0.100 / 0.154 -- the small maps keep the choices below.
+    if (d->mode == MCAV_G_ADJ_REFLECT && ((M + 127) / 128) * ((d->n_count + 63) / 64) >= 1024) return 2;
     // measured on MI355X (tools/conv_bench.py): small output tiles with 32-deep K-tiles win at every layer shape of the step --
     // more co-resident workgroups hide the load round trips, and a 32-deep tile halves the barriers per FLOP
     if (d->mode != MCAV_G_SMALLC && ((M + 127) / 128) * ((d->n_count + 63) / 64) >= 1024) return 1;   // many rows (layer1, 48x160): 128x64 tiles, 104 vs 96 TF/s
@@ -1666,11 +1670,13 @@ inline void launch_igemm(const IgemmParams& p, hipStream_t s) {
 using namespace mcav;
 
 int mcav_bf16_igemm_mtiles(const mcav_igemm_desc* d);             // conv_bf16.hip: 0 = the launch does not run there
+int mcav_stem_mtiles(const mcav_igemm_desc* d);                   // conv_stem.hip: 0 = not the image stem
 
 MCAV_EXPORT int mcav_igemm_mtiles(const mcav_igemm_desc* d) {
     IgemmParams p;
     int tile;
     if (!fill_params(d, p, tile)) return MCAV_E_INVALID;
+    if (const int st = mcav_stem_mtiles(d)) return st;             // the stem kernel's 8 x 32 output tiles
     if (d->mma == 1) {                                             // the bf16 kernels choose their own tile shape
         const int mt = mcav_bf16_igemm_mtiles(d);
         if (mt > 0) return mt;
@@ -1680,6 +1686,8 @@ MCAV_EXPORT int mcav_igemm_mtiles(const mcav_igemm_desc* d) {
 
 bool mcav_try_halo(const mcav_igemm_desc* d, hipStream_t s);      // conv_halo.hip: narrow high-resolution 3x3 layers (forward and reflect-adjoint)
 int mcav_bf16_igemm(const mcav_igemm_desc* d, hipStream_t s);      // conv_bf16.hip: 1 = not eligible
+bool mcav_try_stem(const mcav_igemm_desc* d, const mcav::IgemmParams& p, hipStream_t s);      // conv_stem.hip: the 7x7 stride-2 image stem
+int mcav_stem_mtiles(const mcav_igemm_desc* d);
 bool mcav_bf16_wgrad_plan(const mcav_wgrad_desc* d, mcav::WgradPlan& pl);
 void mcav_bf16_wgrad_launch(const mcav::WgradParams& p, hipStream_t s);
 
@@ -1689,6 +1697,7 @@ MCAV_EXPORT int mcav_igemm(const mcav_igemm_desc* d, void* stream) {
     if (!fill_params(d, p, tile)) return MCAV_E_INVALID;
     hipStream_t s = as_stream(stream);
     if (mcav_try_halo(d, s)) return launch_status();
+    if (mcav_try_stem(d, p, s)) return launch_status();
     if (d->mma == 1) {                                   // bf16 MFMA tiles (conv_bf16.hip) where the launch qualifies, else the fp32 kernels below
         const int rc = mcav_bf16_igemm(d, s);
         if (rc != 1) return rc;
@@ -1714,6 +1723,8 @@ MCAV_EXPORT int mcav_igemm(const mcav_igemm_desc* d, void* stream) {
 namespace mcav {
 
 }  // namespace mcav
+int mcav_stem_wgrad_splits(const mcav_wgrad_desc* d);
+void mcav_stem_wgrad_launch(const mcav_wgrad_desc* d, float* slab, int Ktot, int slabN, int splits, hipStream_t s);
 int mcav_halo_wgrad_splits(const mcav_wgrad_desc* d);
 void mcav_halo_wgrad_launch(const mcav_wgrad_desc* d, float* slab, int slabN, int splits, hipStream_t s);
 namespace mcav {
@@ -1796,6 +1807,9 @@ bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     const int halo_splits = p.upm ? 0 : mcav_halo_wgrad_splits(d);      // narrow high-resolution layers: conv_halo.hip writes the slab partials
     pl.use_halo = halo_splits > 0;
     if (pl.use_halo) { p.splits = halo_splits; pl.use_tab = false; }
+    const int stem_splits = p.upm ? 0 : mcav_stem_wgrad_splits(d);      // the image stem: conv_stem.hip writes the slab partials
+    pl.use_stem = stem_splits > 0;
+    if (pl.use_stem) { p.splits = stem_splits; pl.use_tab = false; }
     p.want_bias = d->dbias != nullptr;
     pl.slab_bytes = align_up(sizeof(float) * (size_t)p.splits * (p.Ktot + 1) * p.slabN, 256);
     pl.groups = p.splits > 8 ? 8 : 0;                            // two-level reduction above 8 splits
@@ -1845,6 +1859,7 @@ MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t wor
     hipStream_t s = as_stream(stream);
     pl.p.slab = reinterpret_cast<float*>(workspace);
     if (bf16) mcav_bf16_wgrad_launch(pl.p, s);
+    else if (pl.use_stem) mcav_stem_wgrad_launch(d, pl.p.slab, pl.p.Ktot, pl.p.slabN, pl.p.splits, s);
     else if (pl.use_halo) mcav_halo_wgrad_launch(d, pl.p.slab, pl.p.slabN, pl.p.splits, s);
     else switch (pl.tile) {
         case 1: launch_wgrad<Tile128x64>(pl.p, pl.use_tab, s); break;

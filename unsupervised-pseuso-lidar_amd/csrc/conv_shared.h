@@ -216,6 +216,7 @@ struct WgradPlan {
     int tile;
     bool use_tab;
     bool use_halo;
+    bool use_stem;                 // conv_stem.hip: the 7x7 stride-2 image stem's own weight-gradient kernel
     size_t slab_bytes, pre_bytes;
     int ci_t, groups, per_group;
 };

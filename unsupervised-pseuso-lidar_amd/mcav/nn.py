@@ -23,7 +23,7 @@ class IgemmDesc(ctypes.Structure):
                 ("mode", c_i), ("stride", c_i), ("sign", c_i), ("offset", c_i), ("pad_mode", c_i),
                 ("y", c_p), ("Hd", c_i), ("Wd", c_i), ("Cd", c_i), ("n_begin", c_i), ("n_count", c_i), ("y_choff", c_i),
                 ("bias", c_p), ("act", c_i), ("dact_aux", c_p), ("dact", c_i), ("addend", c_p), ("pool", c_i), ("stats", c_p),
-                ("tile", c_i), ("groups", c_i), ("w_upmerge", c_p), ("mma", c_i), ("w16", c_p)]
+                ("tile", c_i), ("groups", c_i), ("w_upmerge", c_p), ("mma", c_i), ("w16", c_p), ("w_stem", c_p)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -41,6 +41,7 @@ L.register({
     "mcav_igemm_uses_bf16": (c_i, [ctypes.POINTER(IgemmDesc)]),
     "mcav_wgrad_uses_bf16": (c_i, [ctypes.POINTER(WgradDesc)]),
     "mcav_f32_to_bf16": (c_i, [c_p, c_p, c_sz, c_p]),
+    "mcav_pack_stem_weights": (c_i, [c_p, c_p, c_p]),
     "mcav_wgrad_workspace_bytes": (c_sz, [ctypes.POINTER(WgradDesc)]),
     "mcav_wgrad": (c_i, [ctypes.POINTER(WgradDesc), c_p, c_sz, c_p]),
     "mcav_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
@@ -243,6 +244,16 @@ class ConvSpec:
     def packed_bwd16(self):
         return self._packed("b16")
 
+    def packed_stem(self):
+        """[168][64] copy of the 7x7 image-stem filter in the K order of csrc/conv_stem.hip (mcav_pack_stem_weights); one tiny launch when stale."""
+        key = self._key()
+        if getattr(self, "_stem", None) is None or self._key_s != key or self._stem.device != self.weight.device:
+            if getattr(self, "_stem", None) is None or self._stem.device != self.weight.device:
+                self._stem = empty((168, 64), self.weight)
+            L.check(L.lib().mcav_pack_stem_weights(P(self.weight), P(self._stem), L.stream()), "mcav_pack_stem_weights")
+            self._key_s = key
+        return self._stem
+
     def packed_upmerge(self, c1):
         """Merged-tap copy for conv(cat(up2(x1), x2)) with reflection padding: [4 classes][Np][4 taps][c1] pre-summed filters of the
         first c1 input channels (mcav_pack_weights_upmerge).  Small (one launch when stale); used on the forward stream only."""
@@ -329,6 +340,8 @@ def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0, gr
     d.tile = tile
     d.groups = groups if stats else 1
     _weights_for(spec, d, False)
+    if spec.smallc and (spec.cout, spec.cin, spec.kh, spec.kw, spec.stride, spec.pad) == (64, 3, 7, 7, 2, 3) and not (tile >> 9) & 1:
+        d.w_stem = P(spec.packed_stem())               # the image stem: patch-in-LDS kernel (tile bit 9 keeps the general one)
     if (up1 and x2 is not None and not stats and spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad == 1
             and spec.pad_mode == PAD_REFLECT and C1 % 16 == 0 and not (tile >> 11) & 1 and not d.mma):
         d.w_upmerge = P(spec.packed_upmerge(C1))       # the upsampled part as 4 merged taps on the low-resolution x1 (tile bit 11: off)

@@ -192,7 +192,13 @@ class _DispResNetPairFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xa, xb, mod, *params):
-        x4 = torch.cat([_to_nhwc4(xa), _to_nhwc4(xb)], 0)
+        xa, xb = L.dev(xa.contiguous(), "image"), L.dev(xb.contiguous(), "image")
+        if xa.shape != xb.shape or xa.shape[1] != 3:
+            raise L.MCAVError("forward_pair: two [B,3,H,W] image batches of one shape")
+        B = xa.shape[0]
+        x4 = torch.zeros((2 * B, xa.shape[2], xa.shape[3], 4), dtype=torch.float32, device=xa.device)      # (the kernel keeps channel 3 as it finds it)
+        N.nchw_to_nhwc(xa, 4, x4[:B])                  # both passes into ONE stacked NHWC4 buffer (no concatenation pass)
+        N.nchw_to_nhwc(xb, 4, x4[B:])
         feats, esv = E.encoder_forward(mod.encoder.encoder, x4, mod.training, groups=2)
         disps, dsv = E.decoder_forward(mod.decoder, feats, (0,))
         ctx.mod, ctx.esv, ctx.dsv = mod, esv, dsv
