@@ -22,7 +22,7 @@ constexpr int ST_KS = 3 * 7 * 4;                  // 84 k-steps (channel, ky, co
 constexpr int ST_N = 64;
 using StemTile = Tile<256, 64, 64, 64, 32, 16>;   // for the shared epilogue: four wavefronts stacked along M, 2 x 2 accumulator tiles each
 
-__global__ __launch_bounds__(256) void stem7x7s2_fwd_kernel(IgemmParams p, const float* __restrict__ wk, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, 2) void stem7x7s2_fwd_kernel(IgemmParams p, const float* __restrict__ wk, int tiles_x, int tiles_y) {
     __shared__ __attribute__((aligned(16))) float sP[3][ST_PR][2][ST_PC];       // 18144 B
     __shared__ __attribute__((aligned(16))) float sW[2 * ST_KS][ST_N];          // 43008 B
     __shared__ int s_out[256];
@@ -30,66 +30,98 @@ __global__ __launch_bounds__(256) void stem7x7s2_fwd_kernel(IgemmParams p, const
     static_assert(sizeof(float) * 3 * ST_PR * 2 * ST_PC >= sizeof(float) * 4 * 2 * ST_N, "statistics scratch fits the patch");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int mt = blockIdx.x;
-    const int per_img = tiles_x * tiles_y;
-    const int b = mt / per_img, tr = mt - b * per_img;
-    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
-    const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+    const int per_img = tiles_x * tiles_y, ntiles = p.g.B * per_img;
     const GatherSrc& g = p.g;
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(g.x1, (unsigned)((size_t)g.B * g.Hs * g.Ws * 4 * 4));
 
-    // ---- destination pixel of every tile row (row = (2 wave + i) * 32 + px)
+    // ---- the filter slice [168][64], once per (persistent) workgroup; all its loads are issued before the first LDS store
     {
-        const int r = tid, oy = oy0 + (r >> 5), ox = ox0 + (r & 31);
-        s_out[r] = (oy < p.Hd && ox < p.Wd) ? (b * p.Hd + oy) * p.Wd + ox : -1;
+        constexpr int WN4 = (2 * ST_KS * ST_N / 4 + 255) / 256;
+        f32x4 wv[WN4];
+        const __amdgpu_buffer_rsrc_t rsw = make_rsrc(wk, 2 * ST_KS * ST_N * 4);
+#pragma unroll
+        for (int j = 0; j < WN4; ++j) wv[j] = buf_load4(rsw, (unsigned)((tid + 256 * j) * 16));      // past the slice: reads zero, not stored
+#pragma unroll
+        for (int j = 0; j < WN4; ++j)
+            if (tid + 256 * j < 2 * ST_KS * ST_N / 4) reinterpret_cast<f32x4*>(&sW[0][0])[tid + 256 * j] = wv[j];
     }
-    // ---- the input patch: source rows 2 oy0 - 3 .., columns 2 ox0 - 3 ..; out-of-image pixels read as zero (zero padding)
-    const unsigned bytes = (unsigned)((size_t)g.B * g.Hs * g.Ws * 4 * 4);
-    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(g.x1, bytes);
-    const int sy0 = 2 * oy0 - 3, sx0 = 2 * ox0 - 3;
-    for (int i = tid; i < ST_PR * 2 * ST_PC; i += 256) {
-        const int row = i / (2 * ST_PC), col = i - row * (2 * ST_PC);          // col = 2 * index + parity
-        const int sy = sy0 + row, sx = sx0 + col;
-        const bool ok = (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
-        const f32x4 v = buf_load4(rsx, ok ? (unsigned)(((b * g.Hs + sy) * g.Ws + sx) * 16) : OOB);
-        sP[0][row][col & 1][col >> 1] = v.x;
-        sP[1][row][col & 1][col >> 1] = v.y;
-        sP[2][row][col & 1][col >> 1] = v.z;
-    }
-    // ---- the filter slice [168][64]
-    for (int i = tid; i < 2 * ST_KS * ST_N / 4; i += 256) reinterpret_cast<f32x4*>(&sW[0][0])[i] = reinterpret_cast<const f32x4*>(wk)[i];
-    __syncthreads();
-
-    f32x16 acc[2][2];
+    // ---- a tile's input patch: source rows 2 oy0 - 3 .., columns 2 ox0 - 3 ..; out-of-image pixels read as zero (zero padding).  The loads
+    // of tile t + 1 are issued before the MFMA loop of tile t and stored when its readers are done.
+    constexpr int PN = (ST_PR * 2 * ST_PC + 255) / 256;
+    f32x4 pv[PN];
+    auto issue = [&](int t) {
+        const int b = t / per_img, tr = t - b * per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int sy0 = 2 * ty * ST_TH - 3, sx0 = 2 * tx * ST_TW - 3;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+        for (int j = 0; j < PN; ++j) {
+            const int i = tid + 256 * j;
+            const int row = i / (2 * ST_PC), col = i - row * (2 * ST_PC);          // col = 2 * index + parity
+            const int sy = sy0 + row, sx = sx0 + col;
+            const bool ok = t < ntiles && i < ST_PR * 2 * ST_PC && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
+            pv[j] = buf_load4(rsx, ok ? (unsigned)(((b * g.Hs + sy) * g.Ws + sx) * 16) : OOB);
+        }
+    };
     const int px = lane & 31, h = lane >> 5;
     // lane-constant bases; everything else is an immediate after unrolling
     const float* pa = &sP[0][4 * wave][h][px];            // output row 2 wave (source row 4 wave + ky); row 2 wave + 1 is two source rows on
     const float* pb = &sW[h][px];
-    static_for<3>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        static_for<7>([&](auto kyc) {
-            constexpr int ky = decltype(kyc)::value;
+
+    issue(blockIdx.x);
+    for (int mt = blockIdx.x; mt < ntiles; mt += gridDim.x) {
+        const int b = mt / per_img, tr = mt - b * per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+        __syncthreads();                                  // the previous tile's epilogue is done with s_out and the statistics scratch
+        {   // destination pixel of every tile row (row = (2 wave + i) * 32 + px)
+            const int r = tid, oy = oy0 + (r >> 5), ox = ox0 + (r & 31);
+            s_out[r] = (oy < p.Hd && ox < p.Wd) ? (b * p.Hd + oy) * p.Wd + ox : -1;
+        }
 #pragma unroll
-            for (int kxp = 0; kxp < 4; ++kxp) {
-                const int ks = (c * 7 + ky) * 4 + kxp;
-                const float a0 = pa[(c * ST_PR + ky) * 2 * ST_PC + kxp];
-                const float a1 = pa[(c * ST_PR + ky + 2) * 2 * ST_PC + kxp];
-                const float b0 = pb[ks * 2 * ST_N], b1 = pb[ks * 2 * ST_N + 32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int j = 0; j < PN; ++j) {
+            const int i = tid + 256 * j;
+            const int row = i / (2 * ST_PC), col = i - row * (2 * ST_PC);
+            if (i < ST_PR * 2 * ST_PC) {
+                sP[0][row][col & 1][col >> 1] = pv[j].x;
+                sP[1][row][col & 1][col >> 1] = pv[j].y;
+                sP[2][row][col & 1][col >> 1] = pv[j].z;
             }
+        }
+        __syncthreads();
+        issue(mt + gridDim.x);                            // (past the last tile: out-of-range offsets, no memory traffic)
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // operands of k-step s + 1 are read from LDS BEFORE the four MFMAs of step s are issued (a wavefront issues in order: a read placed
+        // right in front of its use leaves the matrix pipe idle for the LDS latency, once per step); the scheduler is fenced so that it
+        // keeps that order
+        float fa0[2], fa1[2], fb0[2], fb1[2];
+        auto rd = [&](auto sc) {
+            constexpr int ks = decltype(sc)::value, kxp = ks & 3, cky = ks >> 2, ky = cky % 7, c = cky / 7, sl = ks & 1;
+            fa0[sl] = pa[(c * ST_PR + ky) * 2 * ST_PC + kxp];
+            fa1[sl] = pa[(c * ST_PR + ky + 2) * 2 * ST_PC + kxp];
+            fb0[sl] = pb[ks * 2 * ST_N];
+            fb1[sl] = pb[ks * 2 * ST_N + 32];
+        };
+        rd(std::integral_constant<int, 0>{});
+        static_for<ST_KS>([&](auto sc) {
+            constexpr int ks = decltype(sc)::value, sl = ks & 1;
+            if constexpr (ks + 1 < ST_KS) rd(std::integral_constant<int, ks + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[sl], fb0[sl], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[sl], fb1[sl], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[sl], fb0[sl], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[sl], fb1[sl], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         });
-    });
-    __syncthreads();                                      // every wavefront is done with the patch: its memory becomes the statistics scratch
-    igemm_epilogue<StemTile>(p, acc, s_out, s_stat, tid, wave * 64, 0, 0, mt);
+        __syncthreads();                                  // every wavefront is done with the patch: its memory becomes the statistics scratch
+        igemm_epilogue<StemTile>(p, acc, s_out, s_stat, tid, wave * 64, 0, 0, mt);
+    }
 }
 
 // OIHW [64][3][7][7] -> [168][64]: row ((c * 7 + ky) * 4 + j) * 2 + h holds w[:, c, ky, 2 j + h] (zero for kx = 7)
@@ -140,40 +172,73 @@ __global__ __launch_bounds__(256) void stem7x7s2_wgrad_kernel(const float* __res
     const __amdgpu_buffer_rsrc_t rsx = make_rsrc(x4, (unsigned)((size_t)B * Hs * Ws * 16));
     const __amdgpu_buffer_rsrc_t rsy = make_rsrc(dy, (unsigned)((size_t)B * Hd * Wd * Cdy * 4));
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int per_img = tiles_x * tiles_y;
+    // every load of a tile is issued before the first LDS store (one memory round trip per tile), and the loads of tile t + 1 are issued
+    // BEFORE the MFMA loop of tile t: they fly while the matrix pipe works and are stored once the tile's readers are done
+    constexpr int PN = (SW_PR * 2 * ST_PC + 255) / 256, DN = SW_TH * ST_TW * (ST_N / 4) / 256;
+    f32x4 pv[PN], dv[DN];
+    const int per_img = tiles_x * tiles_y;
+    auto issue = [&](int t) {
         const int b = t / per_img, tr = t - b * per_img;
         const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
         const int oy0 = ty * SW_TH, ox0 = tx * ST_TW;
         const int sy0 = 2 * oy0 - 3, sx0 = 2 * ox0 - 3;
-        __syncthreads();                                  // the previous tile's readers are done
-        for (int e = tid; e < SW_PR * 2 * ST_PC; e += 256) {
+        const bool live = t < ntiles;
+#pragma unroll
+        for (int j = 0; j < PN; ++j) {
+            const int e = tid + 256 * j;
             const int row = e / (2 * ST_PC), col = e - row * (2 * ST_PC);
             const int sy = sy0 + row, sx = sx0 + col;
-            const bool ok = (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws;
-            const f32x4 v = buf_load4(rsx, ok ? (unsigned)(((b * Hs + sy) * Ws + sx) * 16) : OOB);
-            sP[0][row][col & 1][col >> 1] = v.x;
-            sP[1][row][col & 1][col >> 1] = v.y;
-            sP[2][row][col & 1][col >> 1] = v.z;
+            const bool ok = live && e < SW_PR * 2 * ST_PC && (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws;
+            pv[j] = buf_load4(rsx, ok ? (unsigned)(((b * Hs + sy) * Ws + sx) * 16) : OOB);
         }
-        for (int e = tid; e < SW_TH * ST_TW * (ST_N / 4); e += 256) {          // dy tile: pixels outside the image contribute zero
+#pragma unroll
+        for (int j = 0; j < DN; ++j) {                                          // dy tile: pixels outside the image contribute zero
+            const int e = tid + 256 * j;
             const int pix = e >> 4, c4 = e & 15;
             const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
-            const bool ok = oy < Hd && ox < Wd;
-            const f32x4 v = buf_load4(rsy, ok ? (unsigned)((((b * Hd + oy) * Wd + ox) * Cdy + dy_choff + c4 * 4) * 4) : OOB);
-            *reinterpret_cast<f32x4*>(&sDY[pix][c4 * 4]) = v;
+            const bool ok = live && oy < Hd && ox < Wd;
+            dv[j] = buf_load4(rsy, ok ? (unsigned)((((b * Hd + oy) * Wd + ox) * Cdy + dy_choff + c4 * 4) * 4) : OOB);
         }
-        __syncthreads();
+    };
+    issue(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();                                  // the previous tile's readers are done
 #pragma unroll
-        for (int r = 0; r < SW_TH; ++r) {
-#pragma unroll
-            for (int xp = 0; xp < ST_TW / 2; ++xp) {
-                const int po = (2 * r) * 2 * ST_PC + 2 * xp;                   // pixel (r, 2 xp + h): source row + 2 r, index + 2 xp (+ h in koff)
-                const float bv = pD[(r * ST_TW + 2 * xp) * ST_N];
-#pragma unroll
-                for (int m = 0; m < 3; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(pP[koff[m] + po], bv, acc[m], 0, 0, 0);
+        for (int j = 0; j < PN; ++j) {
+            const int e = tid + 256 * j;
+            const int row = e / (2 * ST_PC), col = e - row * (2 * ST_PC);
+            if (e < SW_PR * 2 * ST_PC) {
+                sP[0][row][col & 1][col >> 1] = pv[j].x;
+                sP[1][row][col & 1][col >> 1] = pv[j].y;
+                sP[2][row][col & 1][col >> 1] = pv[j].z;
             }
         }
+#pragma unroll
+        for (int j = 0; j < DN; ++j) {
+            const int e = tid + 256 * j;
+            *reinterpret_cast<f32x4*>(&sDY[e >> 4][(e & 15) * 4]) = dv[j];
+        }
+        __syncthreads();
+        issue(t + gridDim.x);                             // (past the last tile: out-of-range offsets, no memory traffic)
+        // (operands of pixel pair s + 1 are read before the three MFMAs of pair s are issued, as in the forward kernel)
+        float fa[2][3], fb[2];
+        auto rd = [&](auto sc) {
+            constexpr int st = decltype(sc)::value, r = st / (ST_TW / 2), xp = st % (ST_TW / 2), sl = st & 1;
+            constexpr int po = (2 * r) * 2 * ST_PC + 2 * xp;                   // pixel (r, 2 xp + h): source row + 2 r, index + 2 xp (+ h in koff)
+            fb[sl] = pD[(r * ST_TW + 2 * xp) * ST_N];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) fa[sl][m] = pP[koff[m] + po];
+        };
+        constexpr int NST = SW_TH * ST_TW / 2;
+        rd(std::integral_constant<int, 0>{});
+        static_for<NST>([&](auto sc) {
+            constexpr int st = decltype(sc)::value, sl = st & 1;
+            if constexpr (st + 1 < NST) rd(std::integral_constant<int, st + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sl][m], fb[sl], acc[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
     }
     // ---- one slab partial per workgroup: row = tap * 4 + channel, column = output channel
     float* out = slab + (size_t)blockIdx.x * (Ktot + 1) * slabN;
@@ -208,7 +273,8 @@ bool mcav_try_stem(const mcav_igemm_desc* d, const IgemmParams& p, hipStream_t s
     const int tiles_x = (d->Wd + ST_TW - 1) / ST_TW, tiles_y = (d->Hd + ST_TH - 1) / ST_TH;
     IgemmParams q = p;
     q.groups = 1;                                         // (the statistics rows of a tile are image-major: groups need nothing else)
-    timed_launch(stem7x7s2_fwd_kernel, dim3(d->B * tiles_x * tiles_y), dim3(256), 0, s, q, d->w_stem, tiles_x, tiles_y);
+    const int ntiles = d->B * tiles_x * tiles_y;
+    timed_launch(stem7x7s2_fwd_kernel, dim3(ntiles < 512 ? ntiles : 512), dim3(256), 0, s, q, d->w_stem, tiles_x, tiles_y);      // persistent: 2 per CU
     return true;
 }
 
