@@ -75,8 +75,9 @@ typedef struct mcav_igemm_desc {
                              * merged-tap forms) run the fp32 kernels with w; mcav_igemm_uses_bf16() tells which. */
     const void* w16;        /* mma = 1: bf16 copy of the packed filter, same [Np][kh*kw][Kp] layout and row stride in ELEMENTS
                              * (mcav_pack_weights_multi with transposed | 2, or mcav_f32_to_bf16 of a packed fp32 copy) */
-    const float* w_stem;    /* NULL, or mcav_pack_stem_weights' copy of a [64][3][7][7] filter: the 7x7 stride-2 image stem (SMALLC gather, 64
-                             * output channels) then runs on the patch-in-LDS kernel of conv_stem.hip; ignored by every other launch */
+    const float* w_stem;    /* NULL, or mcav_pack_stem_weights' copy of the filter: the 7x7 stride-2 stems (the image stem: SMALLC gather, 3 -> 64;
+                             * PoseNet conv1: 9 of 16 stored channels -> 16) then run on the patch-in-LDS kernels of conv_stem.hip; ignored by
+                             * every other launch */
 } mcav_igemm_desc;
 
 /* number of M-tiles (rows of `stats`) the launch will use with its chosen tile config */
@@ -131,9 +132,10 @@ int mcav_pack_weights_multi(const void* items_dev, int nitems, int nblocks, void
 /* round-to-nearest-even fp32 -> bf16 of a flat buffer (the special packed copies: merged-tap adjoint filters) */
 int mcav_f32_to_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
 int mcav_pack_weights_blocks(int taps, int transposed, int Np, int Kp);   /* workgroups one record needs */
-/* The image stem's filter (reference resnet_dispnet.py:38: conv1 of the torchvision trunk, OIHW [64][3][7][7]) in the K order of the
- * patch-in-LDS kernel: [168][64], row ((c * 7 + ky) * 4 + j) * 2 + h = w[:, c, ky, 2 j + h], zero rows for the padding column kx = 7. */
-int mcav_pack_stem_weights(const float* w_oihw, float* packed168x64, void* stream);
+/* A 7x7 stride-2 stem filter -- the depth net's conv1 (reference resnet_dispnet.py:38: torchvision resnet, OIHW [64][3][7][7]) or PoseNet's
+ * conv1 (pose_net.py:40: [16][9][7][7]) -- in the K order of the patch-in-LDS kernels: [Cin * 56][Cout], row ((c * 7 + ky) * 4 + j) * 2 + h =
+ * w[:, c, ky, 2 j + h], zero rows for the padding column kx = 7. */
+int mcav_pack_stem_weights(const float* w_oihw, int Cout, int Cin, float* packed, void* stream);
 /* Merged-tap copy of a 3x3 filter for mcav_igemm_desc.w_upmerge: packed [4 parity classes (py, px)][Np][4 merged taps (a, b)][C1] with
  * packed[cls][n][a*2+b][c] = sum of w[n][c][ky][kx] over ky in S(py, a), kx in S(px, b);  S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1},
  * S(1,1) = {2};  c < C1 (the upsampled source's channels = the filter's first C1 input channels); rows n >= Cout are zero. */

@@ -221,6 +221,32 @@ def test_stem_patch_kernels_forward_stats_wgrad(B, H, W):
     assert rel_err(wp.grad, 2 * w.grad) < 5e-5
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 45, 70), (4, 192, 640)])
+def test_pose_stem_patch_kernels(B, H, W):
+    """csrc/conv_stem.hip on PoseNet's conv1 (9 of 16 stored channels -> 16, 7x7 stride 2, bias + ReLU): forward, weight and bias gradient
+    against torch and against the general kernels (desc.tile bit 9)."""
+    from mcav import nn as N
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(B, 9, H, W, generator=g)
+    w = (torch.randn(16, 9, 7, 7, generator=g) * 0.05).requires_grad_()
+    b = (0.1 * torch.randn(16, generator=g)).requires_grad_()
+    pre = F.conv2d(x, w, b, stride=2, padding=3)
+    dy = torch.randn(pre.shape, generator=g)
+    pre.backward(dy)
+    wp, bp = torch.nn.Parameter(w.detach().to(DEV)), torch.nn.Parameter(b.detach().to(DEV))
+    spec = N.ConvSpec(wp, bp, 2, 3, 0)
+    xin = nhwc(x, 16)
+    got = N.conv_fwd(spec, xin, act=N.ACT_RELU)
+    assert getattr(spec, "_stem", None) is not None, "the launch did not take the patch kernel"
+    assert rel_err(nchw(got), F.relu(pre)) < 2e-5
+    assert rel_err(got, N.conv_fwd(spec, xin, act=N.ACT_RELU, tile=0x200)) < 2e-5
+    N.conv_wgrad(spec, xin, nhwc(dy))
+    assert rel_err(wp.grad, w.grad) < 5e-5
+    assert rel_err(bp.grad, b.grad) < 5e-5
+    N.conv_wgrad(spec, xin, nhwc(dy))                  # accumulates
+    assert rel_err(wp.grad, 2 * w.grad) < 5e-5 and rel_err(bp.grad, 2 * b.grad) < 5e-5
+
+
 def test_batchnorm_train_and_backward():
     from mcav import nn as N
     from mcav.holders import BNParams

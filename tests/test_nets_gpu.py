@@ -140,3 +140,21 @@ def test_dispresnet50_vs_oracle():
     hip2 = reinit_by_name(DispResNet50(), 77).to(DEV).train()
     a, b = hip2.forward_pair(x.to(DEV), x.flip(0).contiguous().to(DEV))
     assert rel_err(a[0], want) < 1e-3
+
+
+def test_standalone_upsample():
+    """`upsample` of the reference's call surface (models/depth/layers.py:55-58: nearest x2 on NCHW), forward and backward."""
+    import torch.nn.functional as F
+    from models.depth.layers import upsample
+    g = torch.Generator().manual_seed(21)
+    for shape in ((2, 5, 7, 9), (1, 16, 24, 80)):
+        x = torch.randn(*shape, generator=g)
+        coef = torch.randn(shape[0], shape[1], 2 * shape[2], 2 * shape[3], generator=g)
+        xr = x.clone().requires_grad_()
+        want = F.interpolate(xr, scale_factor=2, mode="nearest")
+        (want * coef).sum().backward()
+        xd = x.to(DEV).requires_grad_()
+        got = upsample(xd)
+        assert torch.equal(got.detach().cpu(), want.detach())
+        (got * coef.to(DEV)).sum().backward()
+        assert rel_err(xd.grad, xr.grad) < 1e-6

@@ -24,4 +24,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_ssim
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_ssim -- python3 $B --steps 2 --warmup 1 --ssim > $OUT/write_ssim.log 2>&1
 python3 $ROOT/tools/pmc_summary.py $OUT/fetch_ssim $OUT/write_ssim $OUT/traffic_ssim.json
 echo ssim pmc done
-rm -rf $OUT/stats $OUT/stats_serial $OUT/fetch $OUT/write $OUT/fetch_ssim $OUT/write_ssim
+rocprofv3 --kernel-trace --stats -d $OUT/stats_bf16 -- python3 $B --steps 10 --warmup 3 --serial --dtype bf16 > $OUT/stats_bf16.log 2>&1
+python3 $ROOT/tools/rocpd_stats.py $(ls $OUT/stats_bf16/*/*_results.db | head -1) $OUT/kernel_stats_serial_bf16.csv
+echo bf16 stats done
+rm -rf $OUT/stats $OUT/stats_serial $OUT/fetch $OUT/write $OUT/fetch_ssim $OUT/write_ssim $OUT/stats_bf16

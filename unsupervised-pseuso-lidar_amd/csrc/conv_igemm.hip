@@ -808,7 +808,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) float Ys[2][KP][BN];   // [pixel][n]      (B operand, k-major)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per_split = p.mtiles * p.ntiles;
-    const int split = blockIdx.x / per_split, rem = blockIdx.x - split * per_split;
+    // XCD-local splits: every row / column tile of one pixel split reads the same pixels (a shifted view of x per tap, the same dy), so
+    // consecutive logical ids share an XCD and the split's pixels are fetched into ONE L2 instead of eight.  On the MFMA-bound fp32 kernels
+    // this changes no launch's time by more than noise (measured in round 1 and again in round 2) but it takes the fabric traffic of the
+    // weight gradients from 2-10x their algorithmic bytes to about 1x (profiles/r02_pmc_fetch_write_per_kernel.txt).
+    const int lid_ = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lid_ / per_split, rem = lid_ - split * per_split;
     const int nt = rem % p.ntiles, mt = rem / p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;      // m0: first kflat row, n0: first output channel
     const GatherSrc& g = p.g;
@@ -1067,7 +1072,12 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
     __shared__ unsigned s_tab[WG_TABCAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per_split = p.mtiles * p.ntiles;
-    const int split = blockIdx.x / per_split, rem = blockIdx.x - split * per_split;
+    // XCD-local splits: every row / column tile of one pixel split reads the same pixels (a shifted view of x per tap, the same dy), so
+    // consecutive logical ids share an XCD and the split's pixels are fetched into ONE L2 instead of eight.  On the MFMA-bound fp32 kernels
+    // this changes no launch's time by more than noise (measured in round 1 and again in round 2) but it takes the fabric traffic of the
+    // weight gradients from 2-10x their algorithmic bytes to about 1x (profiles/r02_pmc_fetch_write_per_kernel.txt).
+    const int lid_ = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lid_ / per_split, rem = lid_ - split * per_split;
     const int nt = rem % p.ntiles, mt = rem / p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const GatherSrc& g = p.g;

@@ -41,7 +41,7 @@ L.register({
     "mcav_igemm_uses_bf16": (c_i, [ctypes.POINTER(IgemmDesc)]),
     "mcav_wgrad_uses_bf16": (c_i, [ctypes.POINTER(WgradDesc)]),
     "mcav_f32_to_bf16": (c_i, [c_p, c_p, c_sz, c_p]),
-    "mcav_pack_stem_weights": (c_i, [c_p, c_p, c_p]),
+    "mcav_pack_stem_weights": (c_i, [c_p, c_i, c_i, c_p, c_p]),
     "mcav_wgrad_workspace_bytes": (c_sz, [ctypes.POINTER(WgradDesc)]),
     "mcav_wgrad": (c_i, [ctypes.POINTER(WgradDesc), c_p, c_sz, c_p]),
     "mcav_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
@@ -102,8 +102,12 @@ PROFILE_TAGS = None
 
 
 class _Timed:
-    def __init__(self, kind, flops, tag=""):
+    """flops: the reference's algorithmic FLOPs of the launch (2 M N K of the convolution it stands for).  executed: what the MFMA pipe really
+    does -- less for the merged-tap forms (4 taps instead of 9 on the upsampled half), more where K is padded (the stem's 168 k for 147)."""
+
+    def __init__(self, kind, flops, tag="", executed=None):
         self.kind, self.flops, self.tag = kind, flops, tag
+        self.executed = flops if executed is None else executed
 
     def __enter__(self):
         if PROFILE is not None:
@@ -112,7 +116,7 @@ class _Timed:
 
     def __exit__(self, *exc):
         if PROFILE is not None:
-            PROFILE.append((self.kind, self.flops, self.i0, L.lib().mcav_kernel_timer_count()))
+            PROFILE.append((self.kind, self.flops, self.i0, L.lib().mcav_kernel_timer_count(), self.executed))
             if PROFILE_TAGS is not None:
                 PROFILE_TAGS.append(self.tag)
         return False
@@ -224,11 +228,20 @@ class ConvSpec:
         if buf is None or self._keys.get(kind) != key or buf.device != self.weight.device:
             taps = self.kh * self.kw
             if buf is None or buf.device != self.weight.device:
+                # first use: derive this one copy (a full repack per new copy would cost ~80 whole-registry launches in the first step)
                 shape = (up16(self.cin), taps * up16(self.cout)) if tr else (self.np, up16(taps * self.kp))
                 buf = torch.empty(shape, dtype=torch.bfloat16 if h else torch.float32, device=self.weight.device)
+                f32 = torch.empty(shape, dtype=torch.float32, device=self.weight.device) if h else buf
+                np_, kp_ = (up16(self.cin), up16(self.cout)) if tr else (self.np, self.kp)
+                L.check(L.lib().mcav_pack_weights(P(self.weight), self.cout, self.cin, self.kh, self.kw, int(tr), P(f32), np_, kp_, L.stream()),
+                        "mcav_pack_weights")
+                if h:
+                    L.check(L.lib().mcav_f32_to_bf16(P(f32), P(buf), f32.numel(), L.stream()), "mcav_f32_to_bf16")
                 self._packs[kind] = buf
+                self._keys[kind] = key
                 PACKS.add(self, kind)
-            PACKS.repack_all(self.weight.device)           # one launch refreshes every registered copy (this one included)
+            else:
+                PACKS.repack_all(self.weight.device)       # one launch refreshes every registered copy (this one included)
         return self._packs[kind]
 
     def packed_fwd(self):
@@ -244,13 +257,18 @@ class ConvSpec:
     def packed_bwd16(self):
         return self._packed("b16")
 
+    def is_stem(self):
+        """The two 7x7 stride-2 stems the patch-in-LDS kernels of csrc/conv_stem.hip cover: the depth net's image stem and PoseNet conv1."""
+        return ((self.kh, self.kw, self.stride, self.pad, self.pad_mode) == (7, 7, 2, 3, PAD_ZERO)
+                and ((self.smallc and (self.cout, self.cin) == (64, 3)) or (not self.smallc and (self.cout, self.cin) == (16, 9))))
+
     def packed_stem(self):
-        """[168][64] copy of the 7x7 image-stem filter in the K order of csrc/conv_stem.hip (mcav_pack_stem_weights); one tiny launch when stale."""
+        """[Cin * 56][Cout] copy of a stem filter in the K order of csrc/conv_stem.hip (mcav_pack_stem_weights); one tiny launch when stale."""
         key = self._key()
         if getattr(self, "_stem", None) is None or self._key_s != key or self._stem.device != self.weight.device:
             if getattr(self, "_stem", None) is None or self._stem.device != self.weight.device:
-                self._stem = empty((168, 64), self.weight)
-            L.check(L.lib().mcav_pack_stem_weights(P(self.weight), P(self._stem), L.stream()), "mcav_pack_stem_weights")
+                self._stem = empty((self.cin * 56, self.cout), self.weight)
+            L.check(L.lib().mcav_pack_stem_weights(P(self.weight), self.cout, self.cin, P(self._stem), L.stream()), "mcav_pack_stem_weights")
             self._key_s = key
         return self._stem
 
@@ -305,6 +323,10 @@ def set_compute_dtype(module, dtype):
     return module
 
 
+def stats_blocks_stem(spec, stats):
+    return stats and not spec.smallc           # (only the image stem's kernel carries the BatchNorm statistics epilogue)
+
+
 def _weights_for(spec, d, transposed):
     """Fills d.w / d.w16 / d.mma of an IgemmDesc whose geometry is already set: the bf16 copy where the launch runs on the bf16 kernels."""
     if spec.mma == MMA_BF16:
@@ -340,8 +362,8 @@ def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0, gr
     d.tile = tile
     d.groups = groups if stats else 1
     _weights_for(spec, d, False)
-    if spec.smallc and (spec.cout, spec.cin, spec.kh, spec.kw, spec.stride, spec.pad) == (64, 3, 7, 7, 2, 3) and not (tile >> 9) & 1:
-        d.w_stem = P(spec.packed_stem())               # the image stem: patch-in-LDS kernel (tile bit 9 keeps the general one)
+    if spec.is_stem() and not stats_blocks_stem(spec, stats) and x2 is None and not up1 and not (tile >> 9) & 1:
+        d.w_stem = P(spec.packed_stem())               # a 7x7 stride-2 stem: patch-in-LDS kernel (tile bit 9 keeps the general one)
     if (up1 and x2 is not None and not stats and spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad == 1
             and spec.pad_mode == PAD_REFLECT and C1 % 16 == 0 and not (tile >> 11) & 1 and not d.mma):
         d.w_upmerge = P(spec.packed_upmerge(C1))       # the upsampled part as 4 merged taps on the low-resolution x1 (tile bit 11: off)
@@ -353,8 +375,14 @@ def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0, gr
             raise L.MCAVError("mcav_igemm_mtiles: invalid descriptor (%d)" % mt)
         slab = empty((mt, 2, spec.cout), x1)
         d.stats = P(slab)
-    with _Timed("fwd", 2.0 * B * Hd * Wd * spec.cout * spec.cin * spec.kh * spec.kw,
-                "M=%d N=%d K=%dx%d s%d %dx%d" % (B * Hd * Wd, spec.cout, spec.cin, spec.kh * spec.kw, spec.stride, Hd, Wd)):
+    flops = 2.0 * B * Hd * Wd * spec.cout * spec.cin * spec.kh * spec.kw
+    executed = flops
+    if d.w_upmerge or (up1 and x2 is None and spec.kh == 3 and spec.pad_mode == PAD_REFLECT and C1 in (16, 32) and spec.cout <= 32
+                       and not (tile >> 10) & 1 and not (tile >> 9) & 1):
+        executed = flops * ((4.0 / 9.0) * C1 + C2) / (C1 + C2)          # upsampled source: 4 merged taps instead of 9 (table kernel / halo kernel)
+    if d.w_stem:
+        executed = flops * (8.0 / 7.0) * (1.0 if spec.cout >= 32 else 2.0)  # the stem's K order pads 7 columns to 8; 16 outputs use half a 32-wide tile
+    with _Timed("fwd", flops, "M=%d N=%d K=%dx%d s%d %dx%d" % (B * Hd * Wd, spec.cout, spec.cin, spec.kh * spec.kw, spec.stride, Hd, Wd), executed):
         L.check(h.mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(fwd)")
     return (y, slab) if stats else y
 
@@ -424,7 +452,8 @@ def _dgrad_upsample_merged(spec, dy, in_shape, c1, dact_aux, dact, addend, tile)
         else:
             d.mma, d.w16 = 0, None
     with _Timed("dgrad", 2.0 * B * Hd * Wd * spec.cout * c1 * 9,
-                "M=%d N=%d K=%dx9 s1 mode2 pool1 (merged 4x4/s2) %dx%d" % (B * Hd * Wd, c1, Cout, Hd, Wd)):
+                "M=%d N=%d K=%dx9 s1 mode2 pool1 (merged 4x4/s2) %dx%d" % (B * Hd * Wd, c1, Cout, Hd, Wd),
+                2.0 * B * (Hl + 2) * (Wl + 2) * spec.cout * c1 * 16):          # 16 taps per low-resolution pixel (incl. the ring) instead of 4 x 9
         L.check(L.lib().mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(dgrad, merged upsample)")
         y = empty((B, Hl, Wl, c1), dy)
         L.check(L.lib().mcav_upsample_adj_fold(P(tmp), B, Hl, Wl, c1, P(dact_aux), dact, P(addend), P(y), L.stream()), "mcav_upsample_adj_fold")
@@ -473,9 +502,14 @@ def conv_wgrad(spec, x1, dy, x2=None, up1=False, tile=0):
         launch_wgrad(d, (x2, dy), flops * c2 / spec.cin, tag + " [skip half]")
         d.x1, d.C1, d.up1, d.Kp = P(x1), c1, 1, c1
         d.Cin, d.ci_offset, d.upm, d.dbias, d.tile = c1, 0, 1, None, 0
-        launch_wgrad(d, (x1, dy), flops * c1 / spec.cin, tag + " [upsampled half, merged taps]")
+        launch_wgrad(d, (x1, dy), flops * c1 / spec.cin, tag + " [upsampled half, merged taps]", flops * c1 / spec.cin * 4.0 / 9.0)
         return
-    launch_wgrad(d, (x1, x2, dy), flops, tag)
+    executed = flops
+    if spec.is_stem() and x2 is None and not up1 and not (tile >> 9) & 1:
+        executed = flops * (8.0 / 7.0) * (1.0 if spec.cout >= 32 else 2.0)
+    elif up1 and x2 is None and spec.kh == 3 and spec.pad_mode == PAD_REFLECT and c1 == 16 and spec.cout <= 16 and not (tile >> 9) & 1:
+        executed = flops * 4.0 / 9.0                                      # level 0: conv3x3_halo_wgrad_up_kernel (merged taps)
+    launch_wgrad(d, (x1, x2, dy), flops, tag, executed)
 
 
 class _WgradSide:
@@ -554,7 +588,7 @@ def grads_ready(params):
         GRADS_READY(list(params))
 
 
-def launch_wgrad(d, tensors, flops=0.0, tag=""):
+def launch_wgrad(d, tensors, flops=0.0, tag="", executed=None):
     """mcav_wgrad for a filled descriptor (workspace handling + stream choice).  tensors: what the launch reads."""
     h = L.lib()
     nbytes = h.mcav_wgrad_workspace_bytes(ctypes.byref(d))
@@ -563,7 +597,7 @@ def launch_wgrad(d, tensors, flops=0.0, tag=""):
 
     def go():
         ws = L.workspace(nbytes, tensors[0].device, "wgrad")
-        with _Timed("wgrad", flops, tag):
+        with _Timed("wgrad", flops, tag, executed):
             L.check(h.mcav_wgrad(ctypes.byref(d), P(ws), ws.numel(), L.stream()), "mcav_wgrad")
     WGRAD_SIDE.run(go, tensors)
 

@@ -102,6 +102,21 @@ class ResnetEncoder(nn.Module):
         self.encoder = ResNet(num_layers)
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
+        if pretrained:
+            # The reference starts from torchvision's ImageNet weights (resnet_dispnet.py:30: a network fetch).  Offline they can only come
+            # from a local file: MCAV_RESNET_WEIGHTS = a torchvision resnet state_dict (.pth; the key names are the same).  Without it the
+            # trunk keeps torchvision's random init, and says so once.
+            import os
+            import warnings
+            path = os.environ.get("MCAV_RESNET_WEIGHTS", "")
+            if path and os.path.exists(path):
+                missing = self.encoder.load_state_dict(torch.load(path, map_location="cpu"), strict=False)
+                if missing.missing_keys:
+                    warnings.warn("ResnetEncoder: %s lacks %d keys (e.g. %s)" % (path, len(missing.missing_keys), missing.missing_keys[0]))
+            elif not getattr(ResnetEncoder, "_warned", False):
+                ResnetEncoder._warned = True
+                warnings.warn("ResnetEncoder(pretrained=True): no ImageNet weights offline (set MCAV_RESNET_WEIGHTS to a torchvision resnet%d "
+                              "state_dict); the trunk starts from random init, unlike the reference" % num_layers)
 
     def forward(self, x):
         """img [B,3,H,W] -> 5 feature maps (NCHW), differentiable w.r.t. the parameters."""

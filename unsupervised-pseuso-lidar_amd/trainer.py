@@ -191,6 +191,12 @@ class Trainer:
     def run_epoch(self):
         for batch_indx, samples in enumerate(self.train_loader):
             self.train_step(samples)
+            if self.step == 1:
+                # the modules, descriptors and packed-weight tables live for the whole run: take them out of the cyclic collector's reach,
+                # so that its full passes (~70 ms over this heap) do not stall the launch queue mid-epoch
+                import gc
+                gc.collect()
+                gc.freeze()
             if self.verbose and self.rank == 0 and (batch_indx % max(1, self.log_freq) == 0):
                 print("epoch %d batch %d loss %.6f" % (self.epoch, batch_indx, float(sum(self.loss).detach())))
         self.model_lr_scheduler.step()
