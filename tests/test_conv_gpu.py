@@ -311,6 +311,7 @@ def test_maxpool_adam_misc():
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 12, 16), (1, 2, 2, 16), (2, 3, 5, 32), (1, 37, 70, 16), (1, 6, 9, 64), (1, 4, 4, 128),
+                                   (2, 3, 130, 16), (1, 33, 65, 32), (3, 17, 16, 64),      # H = 3 (both border rules on one row), ragged tile grids
                                    (1, 256, 256, 16)])      # the last one is large enough for the pre-multiplied-gradient path
 def test_one_channel_head_stencil(shape):
     """The disparity head (3x3 reflect conv to ONE channel + sigmoid): stencil forward and the fused one-pass backward
