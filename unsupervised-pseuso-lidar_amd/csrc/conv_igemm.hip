@@ -349,13 +349,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 // TK = 2 (UPM): forward conv of cat(nearest-up2(x1), x2) with reflection padding, the x1 part as FOUR merged taps on the low-resolution
 // x1 (see mcav_igemm_desc.w_upmerge): rows are grouped by output parity class, the K loop runs 4 * C1/CK tiles from x1 with the
 // class's pre-summed filters and then the usual 9 * C2/CK tiles from x2.  Reflection on the upsampled grid = clamping the source index.
+#ifndef MCAV_DIAG
+#define MCAV_DIAG 0      // > 0: timing-only builds of the steady-state loop (results are wrong): 1 no global loads, 2 no LDS stores either, 3 no barrier
+#endif
+#if MCAV_DIAG == 4      // per-phase shader cycles of the table-driven kernel, summed over workgroups (thread 0): [1] tables | [2] first loads | [3] loop | [4] tail | [5] epilogue; [0] = workgroups
+__device__ unsigned long long g_diag_stamps[8];
+#define MCAV_STAMP_BEGIN() unsigned long long st_prev = __builtin_readcyclecounter()
+#define MCAV_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long st_now = __builtin_readcyclecounter(); \
+        atomicAdd(&g_diag_stamps[i], st_now - st_prev); if (i == 5) atomicAdd(&g_diag_stamps[0], 1ull); st_prev = st_now; } } while (0)
+#else
+#define MCAV_STAMP_BEGIN()
+#define MCAV_STAMP(i)
+#endif
 template <class T, int TK>
 __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     constexpr bool REFL = TK == 1, UPM = TK == 2;
     constexpr int BM = T::BM, BN = T::BN, CKT = T::KD;
     __shared__ __attribute__((aligned(16))) float As[2][BM][T::LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][T::LD];
-    __shared__ int s_out[BM];
+    __shared__ __attribute__((aligned(16))) unsigned s_out[BM];          // byte offset of each tile row's output pixel in y (OOB: no such row)
     // the BatchNorm column-sum scratch of the epilogue borrows the A panel (free once the K loop's last barrier has passed): with it the
     // REFL kind's 64x64 tile fits 40 KB too
     float (*const s_stat)[2][BN] = reinterpret_cast<float (*)[2][BN]>(&As[1][0][0]);
@@ -375,6 +387,7 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     __shared__ int s_nt;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    MCAV_STAMP_BEGIN();
     // The XCD remap gives each XCD one contiguous run of tiles.  Parity-class tiles differ 4x in work per class, and a run is
     // (mostly) one class: there the hardware's round-robin over XCDs is kept, so every XCD gets the same mix, long tiles first.
     const int lid = p.g.mode == MCAV_G_ADJ_STRIDE2 ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
@@ -388,7 +401,7 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
         const bool ok = decode_row(p, m0 + r, n, dy, dx);
         int o = -1;
         if (ok) o = p.pool ? ((n * (p.Hd >> 1) + (dy >> 1)) * (p.Wd >> 1) + (dx >> 1)) : ((n * p.Hd + dy) * p.Wd + dx);
-        s_out[r] = o;
+        s_out[r] = o >= 0 ? (unsigned)o * (unsigned)(p.Cd * 4) : OOB;
         s_rn[r] = ok ? n : -1; s_ry[r] = dy; s_rx[r] = dx;
     }
     if (tid == 0) {      // ADJ_STRIDE2 tiles hold one parity class of destination pixels and visit only that class's taps
@@ -609,26 +622,6 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     constexpr int MFR = T::MF;                                     // fragment rows: 32 (32x32x2) or 16 (16x16x4)
     constexpr int KSUB = MFR == 32 ? 8 : 16;                       // K depth covered by one ds_read_b128 per lane (4 MFMAs)
     const int frow = lane & (MFR - 1), fk = (lane / MFR) * 4;
-    auto compute = [&](auto bufc) {
-        constexpr int buf = decltype(bufc)::value;
-#pragma unroll
-        for (int ks = 0; ks < CKT / KSUB; ++ks) {
-            f32x4 a[T::TM], b[T::TN];
-#pragma unroll
-            for (int i = 0; i < T::TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][wm0 + i * MFR + frow][ks * KSUB + fk]);
-#pragma unroll
-            for (int j = 0; j < T::TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][wn0 + j * MFR + frow][ks * KSUB + fk]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < T::TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < T::TN; ++j) {
-                        if constexpr (MFR == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
-                    }
-        }
-    };
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
 
@@ -651,7 +644,9 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     };
     auto piece = [&](auto pc, auto nxt) {
         constexpr int P = decltype(pc)::value, buf = decltype(nxt)::value;
-        if constexpr (P < T::AROWS) {                                   // A store (+ the reflected contributions of a border wavefront)
+        if constexpr (MCAV_DIAG >= 2 && P < T::AROWS + T::BVECS) {
+            // diagnostic build: no LDS stores either
+        } else if constexpr (P < T::AROWS) {                            // A store (+ the reflected contributions of a border wavefront)
             if constexpr (REFL) {
                 if (wave_border) ra[P] += (ex0[P] + ex1[P]) + ex2[P];
             }
@@ -660,6 +655,8 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
             constexpr int j = P - T::AROWS;
             const int e = tid + 256 * j, nn = e / T::LPR, cb = e % T::LPR;
             if (BFULL || nn < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nn][cb * 4]) = rb[j];
+        } else if constexpr (MCAV_DIAG >= 1 && (P == T::AROWS + T::BVECS || P == T::AROWS + T::BVECS + 2)) {
+            // diagnostic build: the steady-state loop re-uses the registers it has (no global loads)
         } else if constexpr (P == T::AROWS + T::BVECS) {                // A loads of the tile after next
             if constexpr (UPM) {
                 const int cb4 = chunk * CKT * 4;
@@ -741,7 +738,9 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
             }
         }
     };
-    auto step = [&](auto cur, auto nxt) {
+    // ST / IS: the step stores tile t + 1 / issues tile t + 2 (the last two steps of a workgroup have nothing left to store / issue)
+    auto step = [&](auto cur, auto nxt, auto stc, auto isc) {
+        constexpr bool ST = decltype(stc)::value, IS = decltype(isc)::value;
         // The merged-tap and reflection-adjoint kinds keep their loads in one block (cut up, the two-segment loads of the first made the
         // compiler spill the offset arrays; the second measured slower): for them the pieces are the stores, then issue() as a whole.
         constexpr bool WHOLE_ISSUE = TK != 0;
@@ -766,36 +765,54 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
                 constexpr int per = (NP + NSLOT - 1) / NSLOT, lo = S * per < NP ? S * per : NP, hi = lo + per < NP ? lo + per : NP;
                 static_for<hi - lo>([&](auto kc) {
                     constexpr int P = lo + decltype(kc)::value;
-                    if constexpr (WHOLE_ISSUE && P == T::AROWS + T::BVECS) issue(ra, rb);
+                    constexpr bool is_store = P < T::AROWS + T::BVECS;
+                    if constexpr ((is_store && !ST) || (!is_store && !IS)) {}
+                    else if constexpr (WHOLE_ISSUE && P == T::AROWS + T::BVECS) issue(ra, rb);
                     else piece(std::integral_constant<int, P>{}, nxt);
                 });
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
-        __syncthreads();
+        if constexpr (MCAV_DIAG < 3) __syncthreads();
     };
+    MCAV_STAMP(1);
     int t = 0;
+    using Yes = std::true_type;
+    using No = std::false_type;
     if (T_total > 0) {
-        issue(ra, rb);
-        store(ra, rb, B0{});
-        if (T_total > 1) issue(ra, rb);
+        if constexpr (REFL) {                    // (the border wavefronts' extra registers serve one tile at a time)
+            issue(ra, rb);
+            store(ra, rb, B0{});
+            if (T_total > 1) issue(ra, rb);
+        } else {                                 // tiles 0 and 1 in flight together: one memory round trip before the loop instead of two
+            f32x4 ra0[T::AROWS], rb0[T::BVECS];
+            issue(ra0, rb0);
+            if (T_total > 1) issue(ra, rb);
+            store(ra0, rb0, B0{});
+        }
     }
     __syncthreads();
+    MCAV_STAMP(2);
     for (; t + 3 < T_total; t += 2) {
-        step(B0{}, B1{});
-        step(B1{}, B0{});
+        step(B0{}, B1{}, Yes{}, Yes{});
+        step(B1{}, B0{}, Yes{}, Yes{});
     }
-    for (; t < T_total; ++t) {                   // the last one to three tiles
-        if (t & 1) {
-            if (t + 1 < T_total) { store(ra, rb, B0{}); if (t + 2 < T_total) issue(ra, rb); }
-            compute(B1{});
-        } else {
-            if (t + 1 < T_total) { store(ra, rb, B1{}); if (t + 2 < T_total) issue(ra, rb); }
-            compute(B0{});
-        }
-        __syncthreads();
+    MCAV_STAMP(3);
+    // the last one to three tiles run the same interleaved step, without the stores / loads that have no tile left
+    const int rest = T_total - t;
+    if (rest == 3) {
+        step(B0{}, B1{}, Yes{}, Yes{});
+        step(B1{}, B0{}, Yes{}, No{});
+        step(B0{}, B1{}, No{}, No{});
+    } else if (rest == 2) {
+        step(B0{}, B1{}, Yes{}, No{});
+        step(B1{}, B0{}, No{}, No{});
+    } else if (rest == 1) {
+        step(B0{}, B1{}, No{}, No{});
     }
-    igemm_epilogue<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
+    MCAV_STAMP(4);
+    igemm_epilogue_lean<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
+    MCAV_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -1430,11 +1447,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, in
     const int run = CI_T * taps, stride = run + 1;
     const size_t split_stride = (size_t)(Ktot + 1) * slabN;
     const bool col_ok = co0 + tx < slabN;
-    for (int idx = ty; idx < run; idx += 8) {
-        const int tap = idx / CI_T, r = idx - tap * CI_T, ci = ci0 + r;
-        float sum = 0.f;
-        if (ci < Cin && col_ok) {
-            if (upm) {
+    if (upm) {
+        for (int idx = ty; idx < run; idx += 8) {
+            const int tap = idx / CI_T, r = idx - tap * CI_T, ci = ci0 + r;
+            float sum = 0.f;
+            if (ci < Cin && col_ok) {
                 const int ky = tap / 3, kx = tap - ky * 3;
                 for (int cls = 0; cls < 4; ++cls) {
                     const int py = cls >> 1, px = cls & 1;
@@ -1442,13 +1459,44 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, in
                     const float* src = slab + (size_t)((cls * 4 + ta * 2 + tb) * Kp + ci) * slabN + co0 + tx;
                     for (int k = 0; k < splits; ++k) sum += src[(size_t)k * split_stride];
                 }
-            } else {
-                const float* src = slab + (size_t)(tap * Kp + ci) * slabN + co0 + tx;
-#pragma unroll 8
-                for (int k = 0; k < splits; ++k) sum += src[(size_t)k * split_stride];
             }
+            lds[tx * stride + r * taps + tap] = sum;
         }
-        lds[tx * stride + r * taps + tap] = sum;
+    } else {
+        // four filter elements per pass, their split loops interleaved: up to 16 independent loads in flight per lane (one element at a
+        // time, the kernel was bound by the round trip of each dependent add)
+        for (int idx0 = ty; idx0 < run; idx0 += 32) {
+            const float* src[4];
+            float sum[4];
+            int at[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + 8 * u, tap = idx / CI_T, r = idx - tap * CI_T;
+                const bool ok = idx < run && ci0 + r < Cin && col_ok;
+                src[u] = ok ? slab + (size_t)(tap * Kp + ci0 + r) * slabN + co0 + tx : nullptr;
+                at[u] = idx < run ? tx * stride + r * taps + tap : -1;
+                sum[u] = 0.f;
+            }
+            int k = 0;
+            for (; k + 3 < splits; k += 4) {
+                float v[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[u][j] = src[u] ? src[u][(size_t)(k + j) * split_stride] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sum[u] += v[u][j];
+            }
+            for (; k < splits; ++k) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sum[u] += src[u] ? src[u][(size_t)k * split_stride] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (at[u] >= 0) lds[at[u]] = sum[u];
+        }
     }
     if (dbias && blockIdx.y == 0 && ty == 0 && co0 + tx < Cout) {
         const float* src = slab + (size_t)Ktot * slabN + co0 + tx;
@@ -1983,3 +2031,11 @@ MCAV_EXPORT int mcav_pack_weights_multi(const void* items_dev, int nitems, int n
     pack_weights_multi_kernel<<<nblocks, 256, 0, as_stream(stream)>>>(reinterpret_cast<const PackItem*>(items_dev), nitems);
     return launch_status();
 }
+
+#if MCAV_DIAG == 4
+MCAV_EXPORT int mcav_diag_stamps(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(mcav::g_diag_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return MCAV_E_INVALID;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mcav::g_diag_stamps), z, sizeof(z)) != hipSuccess) return MCAV_E_INVALID; }
+    return MCAV_OK;
+}
+#endif

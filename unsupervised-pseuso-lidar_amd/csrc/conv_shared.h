@@ -189,6 +189,125 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, typename T:
     }
 }
 
+// The same epilogue for the table-driven kernels, written for few vector instructions (fp32 MFMAs and the VALU share the SIMD's FMA lanes,
+// so every vector instruction outside the K loop is taken from the other resident workgroups' MFMA time): s_outb holds each tile row's
+// BYTE offset into y (OOB for rows past M), a 4-row group is one 16-byte LDS read, stores / aux loads are raw buffer accesses whose
+// out-of-range offsets are dropped in hardware, and the aux / addend values of a 32x32 block are all loaded before the first use.
+template <class T>
+__device__ __forceinline__ void igemm_epilogue_lean(const IgemmParams& p, typename T::AccT (&acc)[T::TM][T::TN], const unsigned* s_outb,
+                                                    float (*s_stat)[2][T::BN], int tid, int wm0, int wn0, int n0, int mt) {
+    constexpr int BN = T::BN, MF = T::MF, NQ = T::ACC / 4;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ccol = lane & (MF - 1);
+    const unsigned ybytes = (unsigned)((size_t)p.g.B * (p.pool ? (p.Hd >> 1) * (p.Wd >> 1) : p.Hd * p.Wd) * p.Cd * 4);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, ybytes);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.dact_aux ? p.dact_aux : p.y, ybytes);
+    const __amdgpu_buffer_rsrc_t rad = make_rsrc(p.addend ? p.addend : p.y, ybytes);
+    float ssum[T::TN], ssq[T::TN];
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) {
+            __builtin_amdgcn_sched_barrier(0);                // one accumulator block at a time (hoisted across blocks, the aux loads cost 40 registers)
+            const int nl = n0 + wn0 + j * MF + ccol;          // column within this launch
+            if (nl < p.n_count) {
+                const float bv = p.bias ? p.bias[p.n_begin + nl] : 0.f;
+                const unsigned colb = (unsigned)(p.y_choff + nl) * 4u;
+                u32x4 ro[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int rbase = wm0 + i * MF + (MF == 32 ? 8 * q + 4 * (lane >> 5) : 4 * (lane >> 4));
+                    ro[q] = *reinterpret_cast<const u32x4*>(&s_outb[rbase]);
+                }
+                if (p.pool) {
+                    float aux[NQ], add[NQ];
+                    if (p.dact_aux) {
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) aux[q] = buf_load1(rx, ro[q].x + colb);
+                    }
+                    if (p.addend) {
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) add[q] = buf_load1(rad, ro[q].x + colb);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act_fwd(acc[i][j][4 * q + e] + bv, p.act);
+                        float s = (v[0] + v[1]) + (v[2] + v[3]);
+                        if (p.dact_aux) s *= act_bwd(aux[q], p.dact);
+                        if (p.addend) s += add[q];
+                        buf_store1(ry, ro[q].x + colb, s);
+                    }
+                } else {
+                    // half a block (8 rows per lane) at a time: its aux / addend loads are all in flight before the first use
+                    constexpr int QH = NQ >= 2 ? NQ / 2 : 1;
+#pragma unroll
+                    for (int q0 = 0; q0 < NQ; q0 += QH) {
+                        float aux[4 * QH], add[4 * QH];
+                        if (p.dact_aux) {
+#pragma unroll
+                            for (int q = 0; q < QH; ++q)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) aux[4 * q + e] = buf_load1(rx, ro[q0 + q][e] + colb);
+                        }
+                        if (p.addend) {
+#pragma unroll
+                            for (int q = 0; q < QH; ++q)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) add[4 * q + e] = buf_load1(rad, ro[q0 + q][e] + colb);
+                        }
+#pragma unroll
+                        for (int q = 0; q < QH; ++q)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float s = acc[i][j][4 * (q0 + q) + e] + bv;
+                                if (p.act == MCAV_ACT_RELU) s = fmaxf(s, 0.f);
+                                else if (p.act != MCAV_ACT_NONE) s = act_fwd(s, p.act);
+                                if (p.dact_aux) s *= act_bwd(aux[4 * q + e], p.dact);
+                                if (p.addend) s += add[4 * q + e];
+                                buf_store1(ry, ro[q0 + q][e] + colb, s);
+                                if (p.stats) {
+                                    const float sv = ro[q0 + q][e] != OOB ? s : 0.f;
+                                    ssum[j] += sv;
+                                    ssq[j] += sv * sv;
+                                }
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) {
+            if (MF == 32) {
+                ssum[j] += __shfl_xor(ssum[j], 32, 64);
+                ssq[j] += __shfl_xor(ssq[j], 32, 64);
+            } else {
+                ssum[j] += __shfl_xor(ssum[j], 16, 64); ssq[j] += __shfl_xor(ssq[j], 16, 64);
+                ssum[j] += __shfl_xor(ssum[j], 32, 64); ssq[j] += __shfl_xor(ssq[j], 32, 64);
+            }
+            if (lane < MF) {
+                s_stat[wave / T::WAVES_N][0][wn0 + j * MF + lane] = ssum[j];
+                s_stat[wave / T::WAVES_N][1][wn0 + j * MF + lane] = ssq[j];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * BN; e += 256) {
+            const int which = e / BN, col = e - which * BN;
+            if (n0 + col < p.n_count) {
+                float s = 0.f;
+#pragma unroll
+                for (int wmi = 0; wmi < T::WAVES_M; ++wmi) s += s_stat[wmi][which][col];
+                p.stats[((size_t)mt * 2 + which) * p.n_count + n0 + col] = s;
+            }
+        }
+    }
+}
+
 constexpr int TAB_TAPS = 16;     // 3x3 filters, and the 4x4 stride-2 form of the pooled upsample adjoint
 constexpr int WG_TABCAP = 4096;
 

@@ -164,7 +164,7 @@ __device__ __forceinline__ f32x4 relu_mask(f32x4 g, f32x4 y) {
 }
 
 // Per-block partial sums of dz and dz * xhat.  G = C/4 channel groups; a block covers PL = 256 / min(G,256) pixel lanes.
-constexpr int BNR_BLOCKS = 256;
+constexpr int BNR_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* dy, const f32x4* yact, const f32x4* x, const f32x4* mean, const f32x4* invstd,
                                                             int relu, size_t n_pix /* per group */, int C4, float* part /* [groups][blocks][2][C] */) {
     __shared__ f32x4 sh[2][256];
@@ -182,7 +182,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* dy, con
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
         if (pl < PL) {
             const f32x4 mu = mean[g0 + cg], is = invstd[g0 + cg];
-            for (size_t m = pb + pl; m < pe; m += PL) {
+            // four pixels per pass, all their loads issued before the first use (a pass of one pixel left three loads in flight per lane)
+            size_t m = pb + pl;
+            for (; m + 3 * (size_t)PL < pe; m += 4 * (size_t)PL) {
+                f32x4 g[4], xv[4], ya[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const size_t i = (m + (size_t)u * PL) * C4 + g0 + cg;
+                    g[u] = dy[i];
+                    xv[u] = x[i];
+                    if (relu) ya[u] = yact[i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (relu) g[u] = relu_mask(g[u], ya[u]);
+                    s1 += g[u];
+                    s2 += g[u] * ((xv[u] - mu) * is);
+                }
+            }
+            for (; m < pe; m += PL) {
                 const size_t i = m * C4 + g0 + cg;
                 f32x4 g = dy[i];
                 if (relu) g = relu_mask(g, yact[i]);
@@ -211,11 +229,23 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* part
     for (int g = 0; g < groups; ++g) {
         const float* pg = part + (size_t)g * nblk * 2 * C;
         double a = 0.0, b = 0.0;
-        if (c < C)
-            for (int k = slice; k < nblk; k += FIN_SL) {
+        if (c < C) {
+            int k = slice;
+            for (; k + 7 * FIN_SL < nblk; k += 8 * FIN_SL) {          // eight blocks' partials in flight, added in block order
+                float va[8], vb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    va[u] = pg[(size_t)(k + u * FIN_SL) * 2 * C + c];
+                    vb[u] = pg[(size_t)(k + u * FIN_SL) * 2 * C + C + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a += (double)va[u]; b += (double)vb[u]; }
+            }
+            for (; k < nblk; k += FIN_SL) {
                 a += (double)pg[(size_t)k * 2 * C + c];
                 b += (double)pg[(size_t)k * 2 * C + C + c];
             }
+        }
         s1[slice][cl] = a; s2[slice][cl] = b;
         __syncthreads();
         if (slice == 0 && c < C) {

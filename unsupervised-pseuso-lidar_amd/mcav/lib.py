@@ -5,7 +5,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcav_depth.so")
+LIB_PATH = os.environ.get("MCAV_LIB_PATH") or os.path.join(_HERE, "libmcav_depth.so")      # (override: kernel-diagnostic builds, csrc/Makefile `diag`)
 _LIB = None
 
 c_p = ctypes.c_void_p
