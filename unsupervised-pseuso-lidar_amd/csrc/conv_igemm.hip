@@ -1275,17 +1275,6 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
                 else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][q][i], b[s][q][j], acc[i][j], 0, 0, 0);
             }
     };
-    auto compute = [&](auto bufc) {
-        rd(bufc, 0, 0);
-#pragma unroll
-        for (int bt = 0; bt < NB; ++bt) {
-            if (bt + 1 < NB) rd(bufc, (bt + 1) & 1, (bt + 1) * 4);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) mma(bt & 1, q);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
     // Two register stages: while tile t is multiplied, tile t + 1 moves from registers to the other LDS buffer and the loads of tiles
@@ -1318,41 +1307,42 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
             if (u < T_total) fetch();
         }
     };
-    auto pieces_of_slot = [&](auto sc, auto nxt, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
-        constexpr int S = decltype(sc)::value;
+    // fl = ST | 2 IS: the step stores tile t + 1 / issues tile t + 3 (the last steps of a split have no tile left to store / issue)
+    auto pieces_of_slot = [&](auto sc, auto nxt, auto fl, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
+        constexpr int S = decltype(sc)::value, FL = decltype(fl)::value;
         constexpr int lo = S * NPIECE / NSLOT, hi = (S + 1) * NPIECE / NSLOT;
-        if constexpr (lo < hi) {
-            piece(std::integral_constant<int, lo>{}, nxt, ra, rb);
-            if constexpr (lo + 1 < hi) piece(std::integral_constant<int, lo + 1>{}, nxt, ra, rb);
-            if constexpr (lo + 2 < hi) piece(std::integral_constant<int, lo + 2>{}, nxt, ra, rb);
-        }
+        static_for<hi - lo>([&](auto kc) {
+            constexpr int P = lo + decltype(kc)::value;
+            constexpr bool is_store = P < APASS + BPASS;
+            if constexpr (is_store ? (FL & 1) != 0 : (FL & 2) != 0) piece(std::integral_constant<int, P>{}, nxt, ra, rb);
+        });
         static_assert(hi - lo <= 3, "at most three pieces per MFMA slot");
     };
-    auto slot = [&](auto sc, auto nxt, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
+    auto slot = [&](auto sc, auto nxt, auto fl, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {
         constexpr int S = decltype(sc)::value;
         mma((S >> 2) & 1, S & 3);
         __builtin_amdgcn_sched_barrier(0);
-        pieces_of_slot(sc, nxt, ra, rb);
+        pieces_of_slot(sc, nxt, fl, ra, rb);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto step = [&](auto cur, auto nxt, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {      // (ra, rb): the stage of tiles t + 1 and t + 3
+    auto step = [&](auto cur, auto nxt, auto fl, f32x4 (&ra)[APASS], f32x4 (&rb)[BPASS]) {      // (ra, rb): the stage of tiles t + 1 and t + 3
         rd(cur, 0, 0);
         static_assert(NB == 2 || NB == 4, "two or four operand batches per tile");
         if constexpr (NB > 1) rd(cur, 1, 4);
         __builtin_amdgcn_sched_barrier(0);
-        slot(std::integral_constant<int, 0>{}, nxt, ra, rb); slot(std::integral_constant<int, 1>{}, nxt, ra, rb);
-        slot(std::integral_constant<int, 2>{}, nxt, ra, rb); slot(std::integral_constant<int, 3>{}, nxt, ra, rb);
+        slot(std::integral_constant<int, 0>{}, nxt, fl, ra, rb); slot(std::integral_constant<int, 1>{}, nxt, fl, ra, rb);
+        slot(std::integral_constant<int, 2>{}, nxt, fl, ra, rb); slot(std::integral_constant<int, 3>{}, nxt, fl, ra, rb);
         if constexpr (NB > 2) rd(cur, 0, 8);
         __builtin_amdgcn_sched_barrier(0);
-        slot(std::integral_constant<int, 4>{}, nxt, ra, rb); slot(std::integral_constant<int, 5>{}, nxt, ra, rb);
-        slot(std::integral_constant<int, 6>{}, nxt, ra, rb); slot(std::integral_constant<int, 7>{}, nxt, ra, rb);
+        slot(std::integral_constant<int, 4>{}, nxt, fl, ra, rb); slot(std::integral_constant<int, 5>{}, nxt, fl, ra, rb);
+        slot(std::integral_constant<int, 6>{}, nxt, fl, ra, rb); slot(std::integral_constant<int, 7>{}, nxt, fl, ra, rb);
         if constexpr (NB > 2) {
             rd(cur, 1, 12);
             __builtin_amdgcn_sched_barrier(0);
-            slot(std::integral_constant<int, 8>{}, nxt, ra, rb); slot(std::integral_constant<int, 9>{}, nxt, ra, rb);
-            slot(std::integral_constant<int, 10>{}, nxt, ra, rb); slot(std::integral_constant<int, 11>{}, nxt, ra, rb);
-            slot(std::integral_constant<int, 12>{}, nxt, ra, rb); slot(std::integral_constant<int, 13>{}, nxt, ra, rb);
-            slot(std::integral_constant<int, 14>{}, nxt, ra, rb); slot(std::integral_constant<int, 15>{}, nxt, ra, rb);
+            slot(std::integral_constant<int, 8>{}, nxt, fl, ra, rb); slot(std::integral_constant<int, 9>{}, nxt, fl, ra, rb);
+            slot(std::integral_constant<int, 10>{}, nxt, fl, ra, rb); slot(std::integral_constant<int, 11>{}, nxt, fl, ra, rb);
+            slot(std::integral_constant<int, 12>{}, nxt, fl, ra, rb); slot(std::integral_constant<int, 13>{}, nxt, fl, ra, rb);
+            slot(std::integral_constant<int, 14>{}, nxt, fl, ra, rb); slot(std::integral_constant<int, 15>{}, nxt, fl, ra, rb);
         }
         __syncthreads();
     };
@@ -1371,22 +1361,31 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
     auto maybe_build = [&](int tt) {
         if (((tt + 1) & ((1 << cht) - 1)) == 0 && ((tt + 1) >> cht) + 1 < nchunks) build_chunk(((tt + 1) >> cht) + 1);
     };
+    using F3 = std::integral_constant<int, 3>;
+    using F1 = std::integral_constant<int, 1>;
+    using F0 = std::integral_constant<int, 0>;
     for (; t + 4 < T_total; t += 2) {
         maybe_build(t);
-        step(B0{}, B1{}, ra1, rb1);
+        step(B0{}, B1{}, F3{}, ra1, rb1);
         maybe_build(t + 1);
-        step(B1{}, B0{}, ra0, rb0);
+        step(B1{}, B0{}, F3{}, ra0, rb0);
     }
-    for (; t < T_total; ++t) {
-        maybe_build(t);
-        if (t & 1) {
-            if (t + 1 < T_total) { store(ra0, rb0, B0{}); if (t + 3 < T_total) issue(ra0, rb0); }
-            compute(B1{});
-        } else {
-            if (t + 1 < T_total) { store(ra1, rb1, B1{}); if (t + 3 < T_total) issue(ra1, rb1); }
-            compute(B0{});
-        }
-        __syncthreads();
+    // the last one to four tiles: the same interleaved step without the pieces that have no tile left (t is even)
+    const int rest = T_total - t;
+    if (rest == 4) {
+        maybe_build(t);     step(B0{}, B1{}, F3{}, ra1, rb1);
+        maybe_build(t + 1); step(B1{}, B0{}, F1{}, ra0, rb0);
+        maybe_build(t + 2); step(B0{}, B1{}, F1{}, ra1, rb1);
+        maybe_build(t + 3); step(B1{}, B0{}, F0{}, ra0, rb0);
+    } else if (rest == 3) {
+        maybe_build(t);     step(B0{}, B1{}, F1{}, ra1, rb1);
+        maybe_build(t + 1); step(B1{}, B0{}, F1{}, ra0, rb0);
+        maybe_build(t + 2); step(B0{}, B1{}, F0{}, ra1, rb1);
+    } else if (rest == 2) {
+        maybe_build(t);     step(B0{}, B1{}, F1{}, ra1, rb1);
+        maybe_build(t + 1); step(B1{}, B0{}, F0{}, ra0, rb0);
+    } else if (rest == 1) {
+        maybe_build(t);     step(B0{}, B1{}, F0{}, ra1, rb1);
     }
 
     constexpr int MF = T::MF;
@@ -1401,15 +1400,21 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
             if (n0 + tid < p.slabN) slab[(size_t)p.Ktot * p.slabN + n0 + tid] = tsum;
         }
     }
+    // partial tile -> slab: raw buffer stores (rows at or past Ktot fall outside the resource and are dropped): one vector add per value
+    const __amdgpu_buffer_rsrc_t rslab = make_rsrc(slab, (unsigned)((size_t)p.Ktot * p.slabN * 4));
+    const int rowb = p.slabN * 4;
 #pragma unroll
     for (int i = 0; i < T::TM; ++i)
 #pragma unroll
         for (int j = 0; j < T::TN; ++j) {
             const int n = n0 + wn0 + j * MF + ccol;
+            if (n < p.slabN) {
+                const unsigned base = (unsigned)(m0 + wm0 + i * MF + (MF == 32 ? 4 * (lane >> 5) : 4 * (lane >> 4))) * (unsigned)rowb + (unsigned)n * 4u;
 #pragma unroll
-            for (int r = 0; r < T::ACC; ++r) {
-                const int row = m0 + wm0 + i * MF + (MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) : 4 * (lane >> 4) + r);
-                if (row < p.Ktot && n < p.slabN) slab[(size_t)row * p.slabN + n] = acc[i][j][r];
+                for (int r = 0; r < T::ACC; ++r) {
+                    const int dr = MF == 32 ? (r & 3) + 8 * (r >> 2) : r;
+                    buf_store1(rslab, base + (unsigned)(dr * rowb), acc[i][j][r]);      // (the range check covers the vector offset only)
+                }
             }
         }
 }
