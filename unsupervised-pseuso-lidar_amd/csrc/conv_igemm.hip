@@ -1625,7 +1625,10 @@ inline int pick_tile(const mcav_igemm_desc* d, long M) {
     // more co-resident workgroups hide the load round trips, and a 32-deep tile halves the barriers per FLOP
     if (d->mode != MCAV_G_SMALLC && ((M + 127) / 128) * ((d->n_count + 63) / 64) >= 1024) return 1;   // many rows (layer1, 48x160): 128x64 tiles, 104 vs 96 TF/s
     // few 64x64 workgroups (layer4's 6x20 maps, M = 2880): 32x64 tiles double them -- 84 -> 104 TF/s on 512->512
-    if (d->mode != MCAV_G_SMALLC && d->Kp % 32 == 0 && ((M + 63) / 64) * ((d->n_count + 63) / 64) < 512) return 12;
+    // ... when halving the tiles shortens the longest CU's queue: up to 128 tiles (each half on a CU of its own) or 257..511 (two halves
+    // balance better than one whole); in between the halves only pair up on the same CUs (6x20 512->256, 180 tiles: 74 TF/s halved, 87 whole)
+    const long t64 = ((M + 63) / 64) * ((d->n_count + 63) / 64);
+    if (d->mode != MCAV_G_SMALLC && d->Kp % 32 == 0 && (t64 <= 128 || (t64 > 256 && t64 < 512))) return 12;
     if (d->mode != MCAV_G_SMALLC && d->Kp % 32 == 0) return 10;
     const long t128x64 = ((M + 127) / 128) * ((d->n_count + 63) / 64);
     return t128x64 >= 1024 ? 1 : 2;
