@@ -11,6 +11,10 @@ noise (the size of the rounding error fp32 accumulates through the layers).  A R
 flips in SOME fp32 evaluation -- which one is chance (measured on MI355X: HIP 6e-6 vs CPU 2.9e-3 on one pose gradient, HIP 3.5e-4 vs CPU
 5e-6 on one stem gradient, both a single flipped unit) -- and moves every gradient downstream of it by the same discrete amount in the
 perturbed float64 run.  An indexing error of a per cent in one layer stays far outside that envelope.
+
+The step tests add to the envelope the CPU fp32 oracle's own step on inputs perturbed by 1e-5: the pose gradient of the loss moves in
+discrete steps of 2e-4 .. 1.5e-3 (one pixel's L1 sign / SSIM clamp / in-view test changing side), and float64 perturbed by 1e-6 does not
+reach those pixels while either fp32 evaluation does (tools/flip_probe.py; numbers in tests/test_step_gpu.py).
 """
 import copy
 
@@ -48,7 +52,8 @@ class Verdicts:
         self.rows, self.factor, self.floor = [], factor, floor
 
     def add(self, name, hip, cpu32, ref64, perturbed64=()):
-        """perturbed64: the same tensor from float64 runs on 1e-6-perturbed inputs (the envelope); may be empty."""
+        """perturbed64: the same tensor from oracle runs on perturbed inputs (the envelope: float64 at 1e-6, and where a test adds them the
+        fp32 oracle at 1e-5); may be empty."""
         env = max([l2_rel(p, ref64) for p in perturbed64], default=0.0)
         self.rows.append((name, l2_rel(hip, ref64), l2_rel(cpu32, ref64), env))
 

@@ -1547,10 +1547,10 @@ struct PackItem {
     int Cout, Cin, taps, transposed, Np, Kp, Kstride, first_block;   // first_block: prefix sum of pack_blocks() over the preceding items
 };
 
-constexpr int PK_LDS = 12288;                 // floats of staging per block (48 KB)
+constexpr int PK_LDS = 5120;                  // floats of staging per block (20 KB: eight blocks per CU; at 48 KB three blocks left the copies latency-bound)
 constexpr int PK_CO = 64;
 
-__host__ __device__ inline int pack_ci_tile(int taps) { const int t = 192 / taps; return t < 1 ? 1 : (t > 8 ? 8 : t); }
+__host__ __device__ inline int pack_ci_tile(int taps) { const int t = 79 / taps; return t < 1 ? 1 : (t > 8 ? 8 : t); }      // 64 x (tile x taps + 1) <= PK_LDS
 
 __host__ __device__ inline int pack_blocks(int transposed, int taps, int Np, int Kp) {
     if (!(transposed & 1)) return Np;
