@@ -31,7 +31,7 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md); the bf16 conv stage also holds the fp32 launches the bf16 kernels do not cover
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_JSON = os.path.join(REPO, "profiles", "r01_traffic.json")      # rocprofv3 PMC passes (tools/pmc_summary.py)
+TRAFFIC_JSON = os.path.join(REPO, "profiles", "r02_traffic.json")      # rocprofv3 PMC passes (tools/pmc_summary.py)
 
 
 def measured_traffic(steps_in_profile=3):
@@ -40,7 +40,7 @@ def measured_traffic(steps_in_profile=3):
         k = json.load(open(TRAFFIC_JSON))["kernels"]
     except Exception:
         return None, None
-    conv_kernels = ("igemm_kernel", "igemm_tab_kernel", "wgrad_kernel", "wgrad_tab_kernel", "conv3x3_halo", "conv3x3r_c1")
+    conv_kernels = ("igemm_kernel", "igemm_tab_kernel", "wgrad_kernel", "wgrad_tab_kernel", "conv3x3_halo", "conv3x3r_c1", "stem7x7s2")
     conv = sum(v["hbm_bytes_per_launch"] * v["launches"] for n, v in k.items() if any(c in n for c in conv_kernels))
     # The fused loss kernel is also launched as a device-side no-op (backward with unit upstream): take its largest launch.  Its loads are
     # 4 B per lane, an access width the guide leaves uncalibrated: undoubled, FETCH_SIZE equals the compulsory read bytes (11 planes) within
@@ -320,7 +320,7 @@ def main():
                            "executed_note": "frac counts the reference's algorithmic FLOPs (2 M N K of every convolution); executed_frac counts what the MFMA "
                                             "pipe does: 4 / 9 of the upsampled half in the merged-tap launches, 168 / 147 in the stem kernels",
                            "traffic_note": "HBM bytes of the conv stage per step, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the rocprofv3 --pmc passes "
-                                           "in profiles/r01_traffic.json (null when absent)",
+                                           "in profiles/r02_traffic.json (null when absent)",
                            "kernel": "conv stage = implicit-GEMM forward / adjoint, weight-gradient, halo and stencil kernels, all launches of one step; "
                                      "durations from per-dispatch HIP start/stop events",
                            "launches_per_step": len(recs) // 3, "algorithmic_gflop_per_step": round(flops / 1e9, 2),
