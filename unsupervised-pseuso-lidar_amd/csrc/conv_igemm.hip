@@ -350,7 +350,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 // x1 (see mcav_igemm_desc.w_upmerge): rows are grouped by output parity class, the K loop runs 4 * C1/CK tiles from x1 with the
 // class's pre-summed filters and then the usual 9 * C2/CK tiles from x2.  Reflection on the upsampled grid = clamping the source index.
 #ifndef MCAV_DIAG
-#define MCAV_DIAG 0      // > 0: timing-only builds of the steady-state loop (results are wrong): 1 no global loads, 2 no LDS stores either, 3 no barrier
+#define MCAV_DIAG 0      // > 0: timing-only builds (results are wrong; `make diag D=n`): 1 no global loads in the steady-state loop, 2 no LDS stores either,
+                         // 3 no barrier, 4 = correct results + per-phase cycle stamps, 5 no set-up arithmetic (tables point at a few hot lines), 6 and no
+                         // first loads, 8 the real set-up, then the tables redirected as in 5
 #endif
 #if MCAV_DIAG == 4      // per-phase shader cycles of the table-driven kernel, summed over workgroups (thread 0): [1] tables | [2] first loads | [3] loop | [4] tail | [5] epilogue; [0] = workgroups
 __device__ unsigned long long g_diag_stamps[8];
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     const GatherSrc& g = p.g;
 
     // ---- once per workgroup: destination pixel of every tile row, the tap list, the offset tables
-    for (int r = tid; r < BM; r += 256) {
+    for (int r = tid; r < (MCAV_DIAG >= 5 ? 0 : BM); r += 256) {
         int n, dy, dx;
         const bool ok = decode_row(p, m0 + r, n, dy, dx);
         int o = -1;
@@ -404,6 +406,11 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
         s_out[r] = o >= 0 ? (unsigned)o * (unsigned)(p.Cd * 4) : OOB;
         s_rn[r] = ok ? n : -1; s_ry[r] = dy; s_rx[r] = dx;
     }
+    if constexpr (MCAV_DIAG >= 5) {      // timing only: no row decode, no table arithmetic (every entry points at pixel 0), outputs go to row r
+        for (int r = tid; r < BM; r += 256) s_out[r] = (unsigned)(m0 + r) < (unsigned)p.M ? (unsigned)(m0 + r) * (unsigned)(p.Cd * 4) : OOB;
+        for (int e = tid; e < p.taps * BM; e += 256) s_o1[e] = (unsigned)(e & 63) * 64u;
+        if (tid == 0) { for (int t = 0; t <= p.taps; ++t) s_tl[t] = t < p.taps ? t : 0; s_nt = p.taps; }
+    } else
     if (tid == 0) {      // ADJ_STRIDE2 tiles hold one parity class of destination pixels and visit only that class's taps
         int nv = 0;
         const bool adj = g.mode == MCAV_G_ADJ_STRIDE2;
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
             s_o2[e] = n >= 0 ? (unsigned)(((n * g.Hs + sy) * g.Ws + sx) * g.C2) * 4u : OOB;
         }
     }
-    for (int e = tid; e < (UPM ? 0 : p.taps * BM); e += 256) {
+    for (int e = tid; e < (UPM || MCAV_DIAG >= 5 ? 0 : p.taps * BM); e += 256) {
         const int tp = e / BM, r = e - tp * BM;
         const int ky = tp / p.kw, kx = tp - ky * p.kw;
         const int n = s_rn[r], dy = s_ry[r], dx = s_rx[r];
@@ -462,6 +469,12 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     }
     __syncthreads();
 
+#if MCAV_DIAG == 4 || MCAV_DIAG == 8
+    if constexpr (MCAV_DIAG == 8) {      // timing only: the real set-up, then every table entry redirected to the same few hot lines
+        for (int e = tid; e < p.taps * BM; e += 256) s_o1[e] = (unsigned)(e & 63) * 64u;
+        __syncthreads();
+    }
+#endif
     const int ntaps = s_nt;
     const int nchunks = p.Kp / CKT;
     const int nch1 = g.C1 / CKT, nch2 = g.C2 / CKT;      // UPM: K-tiles per merged tap of x1 / per tap of x2
@@ -784,6 +797,12 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
             issue(ra, rb);
             store(ra, rb, B0{});
             if (T_total > 1) issue(ra, rb);
+        } else if constexpr (MCAV_DIAG >= 6) {   // timing only: no first loads
+#pragma unroll
+            for (int j = 0; j < T::AROWS; ++j) ra[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int j = 0; j < T::BVECS; ++j) rb[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+            store(ra, rb, B0{});
         } else {                                 // tiles 0 and 1 in flight together: one memory round trip before the loop instead of two
             f32x4 ra0[T::AROWS], rb0[T::BVECS];
             issue(ra0, rb0);
