@@ -376,12 +376,15 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     static_assert(sizeof(float) * BM * T::LD >= sizeof(float) * T::WAVES_M * 2 * BN, "statistics scratch fits one A buffer");
     // LDS budget: with 32-deep 64x64 tiles everything below fits 40 KB, i.e. FOUR workgroups per CU.  The offset tables are dynamic
     // shared memory sized by the launch (taps x BM x {1, 2} sources); the row coordinates are only needed while the tables are built
-    // and borrow the (not yet used) A panel, except in the REFL kind, whose border wavefronts re-read them inside the loop.
+    // and borrow the (not yet used) A panel (the REFL kind's reflected sources are table rows too: no address arithmetic in the loop).
     extern __shared__ unsigned s_dyn[];
     unsigned* const s_o1 = s_dyn;
     unsigned* const s_o2 = s_dyn + (UPM ? 4 * BM : (p.g.C2 > 0 ? p.taps * BM : 0));      // UPM: 4 merged-tap rows, then the 9 taps of x2
-    __shared__ int s_rows[REFL ? 3 * BM : 1];
-    int* const s_rn = REFL ? s_rows : reinterpret_cast<int*>(&As[0][0][0]);
+    int* const s_rn = reinterpret_cast<int*>(&As[0][0][0]);
+    // REFL: three more tables behind s_o1 -- the reflected sources of the rows next to the border (OOB elsewhere)
+    unsigned* const s_e0 = s_dyn + p.taps * BM;
+    unsigned* const s_e1 = s_dyn + 2 * p.taps * BM;
+    unsigned* const s_e2 = s_dyn + 3 * p.taps * BM;
     int* const s_ry = s_rn + BM;
     int* const s_rx = s_rn + 2 * BM;
     static_assert(2 * BM * T::LD >= 3 * BM, "row coordinates fit the A panel");
@@ -461,6 +464,15 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
                 sx = reflect_idx(sx, g.Ws);
             }
         }
+        if constexpr (REFL) {      // the outputs whose reflected tap landed on this pixel: row 0 / H - 1 seen from rows 1 / H - 2, same for columns
+            const int ey = (dy == 1 && ky == 0) ? 0 : ((dy == g.Hs - 2 && ky == 2) ? g.Hs - 1 : -1);
+            const int ex = (dx == 1 && kx == 0) ? 0 : ((dx == g.Ws - 2 && kx == 2) ? g.Ws - 1 : -1);
+            const bool syok = (unsigned)sy < (unsigned)g.Hs, sxok = (unsigned)sx < (unsigned)g.Ws;
+            const int rowb = n * g.Hs;
+            s_e0[tp * BM + r] = (ok && ey >= 0 && sxok) ? (unsigned)(((rowb + ey) * g.Ws + sx) * g.C1) * 4u : OOB;
+            s_e1[tp * BM + r] = (ok && ex >= 0 && syok) ? (unsigned)(((rowb + sy) * g.Ws + ex) * g.C1) * 4u : OOB;
+            s_e2[tp * BM + r] = (ok && ey >= 0 && ex >= 0) ? (unsigned)(((rowb + ey) * g.Ws + ex) * g.C1) * 4u : OOB;
+        }
         ok = ok && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
         const int pix = (n * g.Hs + sy) * g.Ws + sx;
         const int pix1 = g.up1 ? ((n * (g.Hs >> 1) + (sy >> 1)) * (g.Ws >> 1) + (sx >> 1)) : pix;
@@ -510,6 +522,7 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
     int tap = UPM ? 0 : __builtin_amdgcn_readfirstlane(s_tl[0]);
     int seg = 0;                                 // UPM: 0 = merged taps of x1, 1 = taps of x2
     unsigned oa[T::AROWS], ob[T::AROWS];
+    unsigned oe0[REFL ? T::AROWS : 1], oe1[REFL ? T::AROWS : 1], oe2[REFL ? T::AROWS : 1];
     unsigned boffm[UPM ? T::BVECS : 1];          // UPM: byte offsets into the merged filter copy [cls][Np][4][C1]
     unsigned bcur[UPM ? T::BVECS : 1];           // UPM: the B offsets of the current segment
     __amdgpu_buffer_rsrc_t rsm = rsw;
@@ -535,7 +548,18 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < T::AROWS; ++j) {
             oa[j] = s_o1[tap * BM + r0 + T::RPP * j] + (unsigned)c4 * 16u;      // OOB + 16 c4 is still out of range
-            ob[j] = s_o2[tap * BM + r0 + T::RPP * j] + (unsigned)c4 * 16u;      // (aliases s_o1 when there is no second source)
+            if constexpr (!REFL) ob[j] = s_o2[tap * BM + r0 + T::RPP * j] + (unsigned)c4 * 16u;      // (aliases s_o1 when there is no second source)
+            else ob[j] = oa[j];
+        }
+        if constexpr (REFL) {
+            if (wave_border) {
+#pragma unroll
+                for (int j = 0; j < T::AROWS; ++j) {
+                    oe0[j] = s_e0[tap * BM + r0 + T::RPP * j] + (unsigned)c4 * 16u;
+                    oe1[j] = s_e1[tap * BM + r0 + T::RPP * j] + (unsigned)c4 * 16u;
+                    oe2[j] = s_e2[tap * BM + r0 + T::RPP * j] + (unsigned)c4 * 16u;
+                }
+            }
         }
     };
     refresh();
@@ -576,22 +600,11 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
         }
         if constexpr (REFL) {
             if (wave_border) {
-                const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
                 for (int j = 0; j < T::AROWS; ++j) {
-                    const int r = r0 + T::RPP * j;
-                    const int n = s_rn[r], dy = s_ry[r], dx = s_rx[r];
-                    const int sy = dy + 1 - ky, sx = dx + 1 - kx;
-                    const int ey = (dy == 1 && ky == 0) ? 0 : ((dy == g.Hs - 2 && ky == 2) ? g.Hs - 1 : -1);
-                    const int ex = (dx == 1 && kx == 0) ? 0 : ((dx == g.Ws - 2 && kx == 2) ? g.Ws - 1 : -1);
-                    const bool syok = (unsigned)sy < (unsigned)g.Hs, sxok = (unsigned)sx < (unsigned)g.Ws;
-                    const int rowb = n * g.Hs, cb = c4 * 4;
-                    const unsigned a0 = (unsigned)((((rowb + ey) * g.Ws + sx) * g.C1 + cb) * 4);
-                    const unsigned a1 = (unsigned)((((rowb + sy) * g.Ws + ex) * g.C1 + cb) * 4);
-                    const unsigned a2 = (unsigned)((((rowb + ey) * g.Ws + ex) * g.C1 + cb) * 4);
-                    ex0[j] = buf_load4s(rs1, (n >= 0 && ey >= 0 && sxok) ? a0 : OOB, cbase * 4);
-                    ex1[j] = buf_load4s(rs1, (n >= 0 && ex >= 0 && syok) ? a1 : OOB, cbase * 4);
-                    ex2[j] = buf_load4s(rs1, (n >= 0 && ey >= 0 && ex >= 0) ? a2 : OOB, cbase * 4);
+                    ex0[j] = buf_load4s(rs1, oe0[j], cbase * 4);
+                    ex1[j] = buf_load4s(rs1, oe1[j], cbase * 4);
+                    ex2[j] = buf_load4s(rs1, oe2[j], cbase * 4);
                 }
             }
         }
@@ -696,22 +709,11 @@ __global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
             if constexpr (REFL) {
                 if (wave_border) {
                     const int cbase = chunk * CKT;
-                    const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
                     for (int j = 0; j < T::AROWS; ++j) {
-                        const int r = r0 + T::RPP * j;
-                        const int n = s_rn[r], dy = s_ry[r], dx = s_rx[r];
-                        const int sy = dy + 1 - ky, sx = dx + 1 - kx;
-                        const int ey = (dy == 1 && ky == 0) ? 0 : ((dy == g.Hs - 2 && ky == 2) ? g.Hs - 1 : -1);
-                        const int ex = (dx == 1 && kx == 0) ? 0 : ((dx == g.Ws - 2 && kx == 2) ? g.Ws - 1 : -1);
-                        const bool syok = (unsigned)sy < (unsigned)g.Hs, sxok = (unsigned)sx < (unsigned)g.Ws;
-                        const int rowb = n * g.Hs, cb = c4 * 4;
-                        const unsigned a0 = (unsigned)((((rowb + ey) * g.Ws + sx) * g.C1 + cb) * 4);
-                        const unsigned a1 = (unsigned)((((rowb + sy) * g.Ws + ex) * g.C1 + cb) * 4);
-                        const unsigned a2 = (unsigned)((((rowb + ey) * g.Ws + ex) * g.C1 + cb) * 4);
-                        ex0[j] = buf_load4s(rs1, (n >= 0 && ey >= 0 && sxok) ? a0 : OOB, cbase * 4);
-                        ex1[j] = buf_load4s(rs1, (n >= 0 && ex >= 0 && syok) ? a1 : OOB, cbase * 4);
-                        ex2[j] = buf_load4s(rs1, (n >= 0 && ey >= 0 && ex >= 0) ? a2 : OOB, cbase * 4);
+                        ex0[j] = buf_load4s(rs1, oe0[j], cbase * 4);
+                        ex1[j] = buf_load4s(rs1, oe1[j], cbase * 4);
+                        ex2[j] = buf_load4s(rs1, oe2[j], cbase * 4);
                     }
                 }
             }
@@ -1638,7 +1640,8 @@ inline int pick_tile(const mcav_igemm_desc* d, long M) {
     if (d->n_count <= 32) return 3;
     // The reflection-adjoint kind carries three extra register stages for its border loads: on the 128-row tiles that is 122 VGPRs and two
     // workgroups per CU.  Measured (MI355X, bench.py --layer-report, 96x320 / 48x160 maps): 128x64 0.370 / 0.129 / 0.181 ms, 64x64x32
-    // 0.331 / 0.113 / 0.159, 64x64x16 0.300 / 0.100 / 0.154 -- the small maps keep the choices below.
+    // 0.331 / 0.113 / 0.159, 64x64x16 0.300 / 0.100 / 0.154 -- the small maps keep the choices below.  (Re-measured with the reflected sources
+    // in tables: 64x64x16 0.265 / 0.078 / 0.131, 128x64 0.274 / 0.080 / 0.134, 64x64x32 0.292 / 0.085 / 0.138.)
     if (d->mode == MCAV_G_ADJ_REFLECT && ((M + 127) / 128) * ((d->n_count + 63) / 64) >= 1024) return 2;
     // measured on MI355X (tools/conv_bench.py): small output tiles with 32-deep K-tiles win at every layer shape of the step --
     // more co-resident workgroups hide the load round trips, and a 32-deep tile halves the barriers per FLOP
@@ -1742,9 +1745,10 @@ inline void launch_igemm(const IgemmParams& p, hipStream_t s) {
     // (tall tiles put rows of many image lines into one wavefront: most wavefronts would take the border path, so they keep the general kernel)
     const bool tab_refl = p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0 && p.g.C1 == p.Kp && p.Kp % T::KD == 0 && !p.no_tab && T::AROWS <= 2;
     const size_t tab_bytes = sizeof(unsigned) * (size_t)p.taps * T::BM * (p.g.C2 > 0 ? 2 : 1);
+    const size_t refl_bytes = sizeof(unsigned) * (size_t)p.taps * T::BM * 4;      // + the three tables of reflected sources
     if (p.upm) timed_launch(igemm_tab_kernel<T, 2>, grid, dim3(256), sizeof(unsigned) * 13 * T::BM, s, p);
     else if (tab) timed_launch(igemm_tab_kernel<T, 0>, grid, dim3(256), tab_bytes, s, p);
-    else if (tab_refl) timed_launch(igemm_tab_kernel<T, 1>, grid, dim3(256), tab_bytes, s, p);
+    else if (tab_refl) timed_launch(igemm_tab_kernel<T, 1>, grid, dim3(256), refl_bytes, s, p);
     else if (fast_mode && c4ok) timed_launch(igemm_kernel<T, K_FAST>, grid, dim3(256), 0, s, p);
     else if (p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0) timed_launch(igemm_kernel<T, K_REFLADJ>, grid, dim3(256), 0, s, p);
     else timed_launch(igemm_kernel<T, K_GENERIC>, grid, dim3(256), 0, s, p);
