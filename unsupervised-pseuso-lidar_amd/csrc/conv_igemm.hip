@@ -1103,7 +1103,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 // both through the offset table (dy is not linear in the low-resolution pixel index).  The 16 x Kp result rows are un-merged into
 // the 9 filter taps by the reduce kernel.
 template <class T, bool UPM>
-__global__ __launch_bounds__(256) void wgrad_tab_kernel(WgradParams p) {
+// (register budget: four 64x64 workgroups per CU -- 40 KB of LDS each with the 2048-entry table --, three of the 128x32 ones: 96->32 at
+//  96x320 0.518 -> 0.410 ms, 64->64 at 48x160 0.126 -> 0.119 ms)
+__global__ __launch_bounds__(256, (T::BM == 64 && T::BN == 64) ? 4 : ((T::BM == 128 && T::BN == 32) ? 3 : 1)) void wgrad_tab_kernel(WgradParams p) {
     constexpr int BM = T::BM, BN = T::BN;
     __shared__ __attribute__((aligned(16))) float Xs[2][KP][BM];
     __shared__ __attribute__((aligned(16))) float Ys[2][KP][BN];

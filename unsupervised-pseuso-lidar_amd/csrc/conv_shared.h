@@ -309,7 +309,7 @@ __device__ __forceinline__ void igemm_epilogue_lean(const IgemmParams& p, typena
 }
 
 constexpr int TAB_TAPS = 32;     // 3x3 filters, the 4x4 stride-2 form of the pooled upsample adjoint, PoseNet's 5x5
-constexpr int WG_TABCAP = 4096;
+constexpr int WG_TABCAP = 2048;
 
 struct WgradParams {
     GatherSrc g;
