@@ -364,7 +364,7 @@ __device__ unsigned long long g_diag_stamps[8];
 #define MCAV_STAMP(i)
 #endif
 template <class T, int TK>
-__global__ __launch_bounds__(256) void igemm_tab_kernel(IgemmParams p) {
+__global__ __launch_bounds__(256, (T::BM == 128 && T::BN == 64 && T::KD == 16 && TK != 1) ? 4 : 1) void igemm_tab_kernel(IgemmParams p) {
     constexpr bool REFL = TK == 1, UPM = TK == 2;
     constexpr int BM = T::BM, BN = T::BN, CKT = T::KD;
     __shared__ __attribute__((aligned(16))) float As[2][BM][T::LD];
