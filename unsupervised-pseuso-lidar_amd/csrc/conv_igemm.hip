@@ -1639,7 +1639,9 @@ inline int kstride_of(int taps, int Kp) { return round_up(taps * Kp, CK); }
 inline int pick_tile(const mcav_igemm_desc* d, long M) {
     if (d->tile) return d->tile;
     if (d->n_count <= 16) return M >= 256 * 64 ? 4 : 6;
-    if (d->n_count <= 32) return 3;
+    // 32 output channels: 128x32 tiles (31 KB of LDS with the table, five workgroups per CU) beat 256x32 (56-60 KB, two) on every such
+    // launch of the step: 96->32 @96x320 merged-tap forward 0.333 -> 0.289 ms, its pooled adjoint 0.089 -> 0.071, 64->32 @48x160 0.081 -> 0.070
+    if (d->n_count <= 32) return 7;
     // The reflection-adjoint kind carries three extra register stages for its border loads: on the 128-row tiles that is 122 VGPRs and two
     // workgroups per CU.  Measured (MI355X, bench.py --layer-report, 96x320 / 48x160 maps): 128x64 0.370 / 0.129 / 0.181 ms, 64x64x32
     // 0.331 / 0.113 / 0.159, 64x64x16 0.300 / 0.100 / 0.154 -- the small maps keep the choices below.  (Re-measured with the reflected sources
