@@ -1855,7 +1855,7 @@ bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     int tile = d->tile & 0xff;
     if (!tile) {
         if (d->Cout <= 16) tile = round_up(p.Ktot, 64) < round_up(p.Ktot, 256) ? 6 : 4;
-        else if (d->Cout <= 32) tile = (d->C2 > 0 && d->C1 % 64 != 0) ? 7 : 3;
+        else if (d->Cout <= 32) tile = 7;      // 128x32 (48 KB of LDS, three workgroups per CU; 256x32 needs 80 KB): 16x25 -> 32 0.052 -> 0.044 ms
         else tile = 2;            // 64x64 beats 128x64 on every layer shape of the step (tools/conv_bench.py wgrad)
     }
     if (p.upm) tile = d->Cout <= 16 ? 6 : 2;                     // 64-row tiles: a row tile never straddles a parity class (4 Kp rows each)
