@@ -1866,11 +1866,36 @@ bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     p.mtiles = (p.Ktot + BM - 1) / BM;
     p.ntiles = (d->Cout + BN - 1) / BN;
     const int out_tiles = p.mtiles * p.ntiles;
-    static const int target_wgs = [] { const char* e = getenv("MCAV_WGRAD_TARGET_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
-    int splits = (target_wgs + out_tiles - 1) / out_tiles;       // aim at ~1024 workgroups (tuning knob: MCAV_WGRAD_TARGET_WGS)
-    const int max_splits = (p.Mpix + 8 * KP - 1) / (8 * KP);     // but at least 8 K-tiles each
+    static const int target_wgs = [] { const char* e = getenv("MCAV_WGRAD_TARGET_WGS"); const int v = e ? atoi(e) : 0; return v; }();
+    int max_splits = (p.Mpix + 8 * KP - 1) / (8 * KP);           // at least 8 K-tiles each
+    if (max_splits > 512) max_splits = 512;
+    if (max_splits < 1) max_splits = 1;
+    int splits;
+    if (target_wgs > 0) {                                        // tuning knob: aim at that many workgroups
+        splits = (target_wgs + out_tiles - 1) / out_tiles;
+    } else {
+        // Whole generations of resident workgroups: 1044 workgroups on 1024 slots (128->128 at 24x80 with "about 1024") run a second
+        // generation for 2 % of the work (0.142 ms; 0.124 at twice the splits).  Take the fewest splits, from one generation's worth up to
+        // three, whose workgroup count fills its last generation to 95 % (else the best fill).
+        const int occ = tile == 2 ? 4 : (tile == 7 ? 3 : (tile == 6 ? 4 : 2)), slots = 256 * occ;
+        auto wgs_of = [&](int sp) {
+            const int pps = round_up((p.Mpix + sp - 1) / sp, KP);
+            return out_tiles * ((p.Mpix + pps - 1) / pps);
+        };
+        int lo = slots / out_tiles, hi = 3 * slots / out_tiles + 1;
+        if (lo < 1) lo = 1;
+        if (lo > max_splits) lo = max_splits;
+        if (hi > max_splits) hi = max_splits;
+        splits = lo;
+        double best = -1.0;
+        for (int sp = lo; sp <= hi; ++sp) {
+            const int w = wgs_of(sp), gens = (w + slots - 1) / slots;
+            const double fill = (double)w / ((double)gens * slots);
+            if (fill > best + 1e-9) { best = fill; splits = sp; }
+            if (fill >= 0.95) { splits = sp; break; }
+        }
+    }
     if (splits > max_splits) splits = max_splits;
-    if (splits > 512) splits = 512;
     if (splits < 1) splits = 1;
     p.pix_per_split = round_up((p.Mpix + splits - 1) / splits, KP);
     // table-driven kernel: the per-workgroup offset table (pixels of a split x taps touched by a row tile x sources) must fit
