@@ -594,12 +594,25 @@ bool mcav_bf16_wgrad_plan(const mcav_wgrad_desc* d, WgradPlan& pl) {
     WgradParams& p = pl.p;
     if ((p.CoutLoad & 3) != 0) return false;
     const int out_tiles = p.mtiles * p.ntiles;
-    int splits = (1024 + out_tiles - 1) / out_tiles;
-    const int max_splits = (p.Mpix + 4 * KPB - 1) / (4 * KPB);
-    if (splits > max_splits) splits = max_splits;
-    if (splits > 512) splits = 512;
-    if (splits < 1) splits = 1;
-    p.pix_per_split = ((p.Mpix + splits - 1) / splits + KPB - 1) / KPB * KPB;
+    // whole generations of the 1024 resident workgroups (four per CU), as plan_wgrad does: the fewest splits whose last generation is 95 % full
+    int max_splits = (p.Mpix + 4 * KPB - 1) / (4 * KPB);
+    if (max_splits > 512) max_splits = 512;
+    if (max_splits < 1) max_splits = 1;
+    const int slots = 1024;
+    auto pps_of = [&](int sp) { return ((p.Mpix + sp - 1) / sp + KPB - 1) / KPB * KPB; };
+    int lo = slots / out_tiles, hi = 3 * slots / out_tiles + 1;
+    if (lo < 1) lo = 1;
+    if (lo > max_splits) lo = max_splits;
+    if (hi > max_splits) hi = max_splits;
+    int splits = lo;
+    double best = -1.0;
+    for (int sp = lo; sp <= hi; ++sp) {
+        const int w = out_tiles * ((p.Mpix + pps_of(sp) - 1) / pps_of(sp)), gens = (w + slots - 1) / slots;
+        const double fill = (double)w / ((double)gens * slots);
+        if (fill > best + 1e-9) { best = fill; splits = sp; }
+        if (fill >= 0.95) { splits = sp; break; }
+    }
+    p.pix_per_split = pps_of(splits);
     p.splits = (p.Mpix + p.pix_per_split - 1) / p.pix_per_split;
     int ntmax = 1;
     for (int mt = 0; mt < p.mtiles; ++mt) {
