@@ -1638,7 +1638,7 @@ inline int kstride_of(int taps, int Kp) { return round_up(taps * Kp, CK); }
 
 inline int pick_tile(const mcav_igemm_desc* d, long M) {
     if (d->tile) return d->tile;
-    if (d->n_count <= 16) return M >= 256 * 64 ? 4 : 6;
+    if (d->n_count <= 16) return (M >= 256 * 64 && d->kh * d->kw <= 16) ? 4 : 6;      // (a 25-tap table for 256 rows is 26 KB of LDS: 64x16 tiles, 0.071 -> 0.051 ms)
     // 32 output channels: 128x32 tiles (31 KB of LDS with the table, five workgroups per CU) beat 256x32 (56-60 KB, two) on every such
     // launch of the step: 96->32 @96x320 merged-tap forward 0.333 -> 0.289 ms, its pooled adjoint 0.089 -> 0.071, 64->32 @48x160 0.081 -> 0.070
     if (d->n_count <= 32) return 7;
