@@ -118,6 +118,8 @@ struct IgemmParams {
     int Np_all;      // packed filter rows (desc.Np)
     int bm;          // rows per tile of the chosen config (UPM row order: tiles of the four classes of one region are adjacent)
     int upm;         // 1: rows are grouped by output parity class and the x1 part of K runs as 4 merged taps on the low-resolution source
+    int ksplit;      // > 1: the K loop of a tile is cut into ksplit workgroups (launches of a handful of tiles: PoseNet's 2x5 .. 6x20 maps);
+    float* kslab;    //      each writes its raw partial tile to kslab[split] (y-shaped), splitk_finish_kernel sums them and applies the epilogue
 };
 
 __device__ __forceinline__ float act_fwd(float v, int act) {

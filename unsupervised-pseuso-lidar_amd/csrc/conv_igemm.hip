@@ -11,6 +11,8 @@
 // Fragments: one ds_read_b128 gives a lane 4 consecutive k of its row; lane-group g takes k = 4g..4g+3 of each
 // 8- (32x32x2) or 16-deep (16x16x4) sub-step, A and B permuted identically, so the products are exact fp32 fmas.
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -396,7 +398,9 @@ __global__ __launch_bounds__(256, (T::BM == 128 && T::BN == 64 && T::KD == 16 &&
     // The XCD remap gives each XCD one contiguous run of tiles.  Parity-class tiles differ 4x in work per class, and a run is
     // (mostly) one class: there the hardware's round-robin over XCDs is kept, so every XCD gets the same mix, long tiles first.
     const int lid = p.g.mode == MCAV_G_ADJ_STRIDE2 ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = lid % p.ntiles, mt = lid / p.ntiles;
+    const int per_split = p.mtiles * p.ntiles;
+    const int ks = p.ksplit > 1 ? lid / per_split : 0, lrem = lid - ks * per_split;      // split of the K loop (ksplit > 1), tile within it
+    const int nt = lrem % p.ntiles, mt = lrem / p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const GatherSrc& g = p.g;
 
@@ -490,7 +494,9 @@ __global__ __launch_bounds__(256, (T::BM == 128 && T::BN == 64 && T::KD == 16 &&
     const int ntaps = s_nt;
     const int nchunks = p.Kp / CKT;
     const int nch1 = g.C1 / CKT, nch2 = g.C2 / CKT;      // UPM: K-tiles per merged tap of x1 / per tap of x2
-    const int T_total = UPM ? 4 * nch1 + 9 * nch2 : ntaps * nchunks;
+    const int T_all = UPM ? 4 * nch1 + 9 * nch2 : ntaps * nchunks;
+    const int t_first = p.ksplit > 1 ? (int)((long)T_all * ks / p.ksplit) : 0;          // this workgroup's K-tiles [t_first, t_first + T_total)
+    const int T_total = p.ksplit > 1 ? (int)((long)T_all * (ks + 1) / p.ksplit) - t_first : T_all;
     const unsigned bytes1 = (unsigned)((size_t)g.B * (g.up1 ? (g.Hs >> 1) * (g.Ws >> 1) : g.Hs * g.Ws) * g.C1 * 4);
     const unsigned bytes2 = (unsigned)((size_t)g.B * g.Hs * g.Ws * g.C2 * 4);
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1, bytes1);
@@ -518,8 +524,8 @@ __global__ __launch_bounds__(256, (T::BM == 128 && T::BN == 64 && T::KD == 16 &&
         wave_border = __any(bd);
     }
     f32x4 ex0[REFL ? T::AROWS : 1], ex1[REFL ? T::AROWS : 1], ex2[REFL ? T::AROWS : 1];
-    int ti = 0, chunk = 0;                       // the ISSUE pointer: next K-tile to load
-    int tap = UPM ? 0 : __builtin_amdgcn_readfirstlane(s_tl[0]);
+    int ti = UPM ? 0 : t_first / nchunks, chunk = UPM ? 0 : t_first - ti * nchunks;      // the ISSUE pointer: next K-tile to load
+    int tap = UPM ? 0 : __builtin_amdgcn_readfirstlane(s_tl[ti]);
     int seg = 0;                                 // UPM: 0 = merged taps of x1, 1 = taps of x2
     unsigned oa[T::AROWS], ob[T::AROWS];
     unsigned oe0[REFL ? T::AROWS : 1], oe1[REFL ? T::AROWS : 1], oe2[REFL ? T::AROWS : 1];
@@ -832,7 +838,14 @@ __global__ __launch_bounds__(256, (T::BM == 128 && T::BN == 64 && T::KD == 16 &&
         step(B0{}, B1{}, No{}, No{});
     }
     MCAV_STAMP(4);
-    igemm_epilogue_lean<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
+    if (p.ksplit > 1) {      // raw partial tile into this split's y-shaped slab; bias / activation / aux factor / addend follow in splitk_finish_kernel
+        IgemmParams q = p;
+        q.y = p.kslab + (size_t)ks * ((size_t)p.g.B * p.Hd * p.Wd * p.Cd);
+        q.bias = nullptr; q.act = MCAV_ACT_NONE; q.dact_aux = nullptr; q.addend = nullptr; q.stats = nullptr;
+        igemm_epilogue_lean<T>(q, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
+    } else {
+        igemm_epilogue_lean<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
+    }
     MCAV_STAMP(5);
 }
 
@@ -1700,6 +1713,7 @@ bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
     if ((long)d->B * d->Hs * d->Ws * (d->C1 > d->C2 ? d->C1 : d->C2) * 4 >= 0x7fffffffL) return false;   // 32-bit byte offsets
     if ((long)d->Np * kstride_of(d->kh * d->kw, d->Kp) * 4 >= 0x7fffffffL) return false;
     p.no_tab = (d->tile >> 8) & 1;
+    p.ksplit = 1; p.kslab = nullptr;
     p.wm = d->w_upmerge; p.Np_all = d->Np; p.upm = 0;
     tile = pick_tile(d, Mlin) & 0xff;
     if (tile == 0) { mcav_igemm_desc dd = *d; dd.tile = 0; tile = pick_tile(&dd, Mlin); }
@@ -1739,15 +1753,73 @@ bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
     return true;
 }
 
+// y = epilogue(sum of the K-split partials): one element per thread and pass, fixed summation order
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slab, int splits, size_t n, int Cd, float* __restrict__ y,
+                                                            const float* __restrict__ bias, int n_begin, int act, const float* __restrict__ dact_aux,
+                                                            int dact, const float* __restrict__ addend) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int k = 0; k < splits; ++k) v += slab[(size_t)k * n + i];
+        if (bias) v += bias[n_begin + (int)(i % (size_t)Cd)];
+        v = act_fwd(v, act);
+        if (dact_aux) v *= act_bwd(dact_aux[i], dact);
+        if (addend) v += addend[i];
+        y[i] = v;
+    }
+}
+
+// per-stream slab of the K-split launches (grown on demand, never freed; not grown while the stream is being captured)
+inline float* ksplit_slab(hipStream_t s, size_t bytes) {
+    static std::mutex mu;
+    static std::map<hipStream_t, std::pair<void*, size_t>> slabs;
+    std::lock_guard<std::mutex> lock(mu);
+    auto& e = slabs[s];
+    if (e.second < bytes) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess) return nullptr;
+        if (st != hipStreamCaptureStatusNone) {
+            // No allocation inside a capture.  The step is captured on one stream after eager warm-up steps (mcav/graph.py), so a slab of
+            // the warm-up's stream is large enough and nothing else uses it while the graph runs: borrow it (same splits, same bits as eager).
+            for (auto& kv : slabs)
+                if (kv.second.second >= bytes) return reinterpret_cast<float*>(kv.second.first);
+            return nullptr;
+        }
+        void* ptr = nullptr;
+        if (hipMalloc(&ptr, bytes) != hipSuccess) return nullptr;
+        e = {ptr, bytes};          // (the old, smaller slab is left to the launches still queued on it)
+    }
+    return reinterpret_cast<float*>(e.first);
+}
+
 template <class T>
-inline void launch_igemm(const IgemmParams& p, hipStream_t s) {
+inline void launch_igemm(const IgemmParams& p_in, hipStream_t s) {
+    IgemmParams p = p_in;
+    p.ksplit = 1; p.kslab = nullptr;
     const bool c4ok = (p.g.C1 & 3) == 0 && (p.g.C2 & 3) == 0 && (p.g.C2 == 0 || (p.g.C1 & 15) == 0);
-    const int grid = p.mtiles * p.ntiles;
     const bool fast_mode = p.g.mode == MCAV_G_DIRECT || (p.g.mode == MCAV_G_ADJ_STRIDE2 && p.g.C2 == 0) || p.g.mode == MCAV_G_SMALLC;
     const bool tab = (p.g.mode == MCAV_G_DIRECT || (p.g.mode == MCAV_G_ADJ_STRIDE2 && p.g.C2 == 0)) && c4ok && p.taps <= TAB_TAPS &&
                      p.g.C1 + p.g.C2 == p.Kp && p.Kp % T::KD == 0 && (p.g.C2 == 0 || p.g.C1 % T::KD == 0) && !p.no_tab;
     // (tall tiles put rows of many image lines into one wavefront: most wavefronts would take the border path, so they keep the general kernel)
     const bool tab_refl = p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0 && p.g.C1 == p.Kp && p.Kp % T::KD == 0 && !p.no_tab && T::AROWS <= 2;
+    if (tab && !p.upm) {
+        // A handful of tiles with a long K loop (PoseNet conv5-7 and their data gradients: 2 .. 90 tiles of 36 .. 72 K-tiles, one workgroup
+        // per CU working through them alone): K is cut over up to 8 workgroups per tile, splitk_finish_kernel sums the partials (fixed order)
+        // and applies the epilogue.
+        const bool plain = !p.pool && !p.stats && p.groups <= 1 && p.y_choff == 0 && p.n_count == p.Cd && p.n_begin == 0;
+        const int tiles = p.mtiles * p.ntiles, ktiles = p.Kp / T::KD * p.taps;
+        static const int enabled = [] { const char* e = getenv("MCAV_KSPLIT"); return e ? atoi(e) : 1; }();
+        static const int max_tiles = [] { const char* e = getenv("MCAV_KSPLIT_TILES"); return e ? atoi(e) : 256; }();
+        if (enabled && plain && tiles <= max_tiles && ktiles >= 32) {
+            int ksp = 1024 / tiles;
+            if (ksp > 8) ksp = 8;
+            if (ksp > ktiles / 4) ksp = ktiles / 4;
+            if (ksp >= 2) {
+                float* slab = ksplit_slab(s, (size_t)p.g.B * p.Hd * p.Wd * p.Cd * 4 * ksp);
+                if (slab) { p.ksplit = ksp; p.kslab = slab; }
+            }
+        }
+    }
+    const int grid = p.mtiles * p.ntiles * p.ksplit;
     const size_t tab_bytes = sizeof(unsigned) * (size_t)p.taps * T::BM * (p.g.C2 > 0 ? 2 : 1);
     const size_t refl_bytes = sizeof(unsigned) * (size_t)p.taps * T::BM * 4;      // + the three tables of reflected sources
     if (p.upm) timed_launch(igemm_tab_kernel<T, 2>, grid, dim3(256), sizeof(unsigned) * 13 * T::BM, s, p);
@@ -1756,6 +1828,12 @@ inline void launch_igemm(const IgemmParams& p, hipStream_t s) {
     else if (fast_mode && c4ok) timed_launch(igemm_kernel<T, K_FAST>, grid, dim3(256), 0, s, p);
     else if (p.g.mode == MCAV_G_ADJ_REFLECT && c4ok && p.g.C2 == 0) timed_launch(igemm_kernel<T, K_REFLADJ>, grid, dim3(256), 0, s, p);
     else timed_launch(igemm_kernel<T, K_GENERIC>, grid, dim3(256), 0, s, p);
+    if (p.ksplit > 1) {
+        const size_t n = (size_t)p.g.B * p.Hd * p.Wd * p.Cd;
+        const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        timed_launch(splitk_finish_kernel, blocks, dim3(256), 0, s, (const float*)p.kslab, p.ksplit, n, p.Cd, p.y, p.bias, p.n_begin, p.act, p.dact_aux,
+                     p.dact, p.addend);
+    }
 }
 
 }  // namespace mcav
