@@ -40,7 +40,7 @@ def measured_traffic(steps_in_profile=3):
         k = json.load(open(TRAFFIC_JSON))["kernels"]
     except Exception:
         return None, None
-    conv_kernels = ("igemm_kernel", "igemm_tab_kernel", "wgrad_kernel", "wgrad_tab_kernel", "conv3x3_halo", "conv3x3r_c1", "stem7x7s2")
+    conv_kernels = ("igemm_kernel", "igemm_tab_kernel", "wgrad_kernel", "wgrad_tab_kernel", "conv3x3_halo", "conv3x3r_c1", "stem7x7s2", "splitk_finish")
     conv = sum(v["hbm_bytes_per_launch"] * v["launches"] for n, v in k.items() if any(c in n for c in conv_kernels))
     # The fused loss kernel is also launched as a device-side no-op (backward with unit upstream): take its largest launch.  Its loads are
     # 4 B per lane, an access width the guide leaves uncalibrated: undoubled, FETCH_SIZE equals the compulsory read bytes (11 planes) within

@@ -10,7 +10,7 @@ for r in rows:
         continue
     n = r["Name"]
     ms = float(r["TotalDurationNs"]) / steps / 1e6
-    if any(k in n for k in ("igemm", "wgrad_tab", "wgrad_kernel", "wgrad_bf16", "halo", "stem7x7", "conv3x3r")):
+    if any(k in n for k in ("igemm", "wgrad_tab", "wgrad_kernel", "wgrad_bf16", "halo", "stem7x7", "conv3x3r", "splitk_finish")):
         conv += ms
         continue
     other += ms
