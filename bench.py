@@ -31,7 +31,30 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md); the bf16 conv stage also holds the fp32 launches the bf16 kernels do not cover
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_JSON = os.path.join(REPO, "profiles", "r02_traffic.json")      # rocprofv3 PMC passes (tools/pmc_summary.py)
+def _latest(*names):
+    for n in names:
+        if os.path.exists(os.path.join(REPO, "profiles", n)):
+            return os.path.join(REPO, "profiles", n)
+    return os.path.join(REPO, "profiles", names[-1])
+
+
+TRAFFIC_JSON = _latest("r03_traffic.json", "r02_traffic.json")      # rocprofv3 PMC passes (tools/pmc_summary.py)
+ROCPROF_CSV = _latest("r03_kernel_stats_one_stream.csv", "r02_kernel_stats_one_stream.csv")      # rocprofv3 --kernel-trace --stats of `bench.py --serial`
+CONV_KERNELS = ("igemm_kernel", "igemm_tab_kernel", "igemm_bf16", "wgrad_kernel", "wgrad_tab_kernel", "wgrad_bf16", "conv3x3_halo", "conv3x3r_c1",
+                "stem7x7s2", "splitk_finish", "wgrad_reduce", "wgrad_presum", "patch3x3")
+
+
+def rocprof_conv_ms_per_step():
+    """Conv-stage kernel time per step from the committed rocprofv3 summary of the one-stream run (the same kernels the event timer brackets:
+    MFMA GEMMs, halo / stencil / stem kernels, the K-split finish and the weight-gradient slab reduction); steps = launches of the Adam kernel."""
+    import csv
+    try:
+        rows = list(csv.reader(l for l in open(ROCPROF_CSV) if not l.startswith("#")))
+    except Exception:
+        return None
+    steps = sum(int(r[1]) for r in rows[1:] if "adam_kernel" in r[0] or "adam_dev_kernel" in r[0])
+    conv = sum(float(r[2]) for r in rows[1:] if any(c in r[0] for c in CONV_KERNELS))
+    return conv / steps / 1e6 if steps else None
 
 
 def measured_traffic(steps_in_profile=3):
@@ -40,8 +63,7 @@ def measured_traffic(steps_in_profile=3):
         k = json.load(open(TRAFFIC_JSON))["kernels"]
     except Exception:
         return None, None
-    conv_kernels = ("igemm_kernel", "igemm_tab_kernel", "wgrad_kernel", "wgrad_tab_kernel", "conv3x3_halo", "conv3x3r_c1", "stem7x7s2", "splitk_finish")
-    conv = sum(v["hbm_bytes_per_launch"] * v["launches"] for n, v in k.items() if any(c in n for c in conv_kernels))
+    conv = sum(v["hbm_bytes_per_launch"] * v["launches"] for n, v in k.items() if any(c in n for c in CONV_KERNELS))
     # The fused loss kernel is also launched as a device-side no-op (backward with unit upstream): take its largest launch.  Its loads are
     # 4 B per lane, an access width the guide leaves uncalibrated: undoubled, FETCH_SIZE equals the compulsory read bytes (11 planes) within
     # 1 %, so it is NOT doubled here (doubling would claim that every input plane is fetched twice).
@@ -245,6 +267,9 @@ def main():
         starts = [(g, t) for ph, g, t in gc_log if ph == "start"]
         stops = [t for ph, g, t in gc_log if ph == "stop"]
         sys.stderr.write("gc: %s\n" % " ".join("gen%d@%.1fms(%.1fms)" % (g, 1000 * (t - t0), 1000 * (e - t)) for (g, t), e in zip(starts, stops)))
+    # self-validation of the N > 1 line: every rank must hold the same parameters after the timed loop (checked BEFORE rank 0's
+    # instrumented steps, which no other rank takes part in); raises -- and the run prints no line -- when they differ
+    agree = mdist.check_ranks_agree(opt.arena(), loss)
     raw_steps = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     per_step = sorted(raw_steps)
     pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
@@ -272,7 +297,12 @@ def main():
         out["config"]["dp"] = {"rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
                                "gradient_arena_bytes": int(opt.arena().numel) * 4,
                                "allreduce_buckets_bytes": [int(b) for b in (gs.last_buckets if gs is not None else [int(opt.arena().numel) * 4])],
-                               "overlap_with_backward": bool(gs is not None and not getattr(make_step, "graphed", False))}
+                               "overlap_with_backward": bool(gs is not None and not getattr(make_step, "graphed", False)),
+                               "MCAV_DP_OVERLAP": os.environ.get("MCAV_DP_OVERLAP", "1"),
+                               "MCAV_DP_BUCKETS": os.environ.get("MCAV_DP_BUCKETS", "decoder,layer4"),
+                               "MCAV_DP_BUCKET_MB": os.environ.get("MCAV_DP_BUCKET_MB", "0"),
+                               "parameters_equal_across_ranks": agree["parameters_equal_across_ranks"],
+                               "parameter_checksum": agree["parameter_checksum"], "loss_per_rank": agree.get("loss_per_rank")}
 
     if rank == 0 and not args.no_roofline:
         # instrumented step(s): every conv kernel dispatched with its own start/stop HIP events (csrc/kernel_timer.h), on one stream
@@ -321,12 +351,17 @@ def main():
                                             "pipe does: 4 / 9 of the upsampled half in the merged-tap launches, 168 / 147 in the stem kernels",
                            "traffic_note": "HBM bytes of the conv stage per step, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the rocprofv3 --pmc passes "
                                            "in profiles/r02_traffic.json (null when absent)",
-                           "kernel": "conv stage = implicit-GEMM forward / adjoint, weight-gradient, halo and stencil kernels, all launches of one step; "
-                                     "durations from per-dispatch HIP start/stop events",
+                           "kernel": "conv stage = implicit-GEMM forward / adjoint, weight-gradient (GEMM + its slab reduction: presum + reduce), halo and "
+                                     "stencil kernels, all launches of one step; durations from per-dispatch HIP start/stop events",
                            "launches_per_step": len(recs) // 3, "algorithmic_gflop_per_step": round(flops / 1e9, 2),
                            "kernel_ms_per_step": round(ms, 3),
                            "by_kind": {k: {"gflop": round(v[0] / 1e9, 2), "ms": round(v[1], 3), "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2),
                                            "launches": v[2] // 3} for k, v in by_kind.items()}}
+        rp_ms = rocprof_conv_ms_per_step() if (B, H, W, args.depth_layers, args.dtype, args.ssim) == (12, 192, 640, 18, "fp32", False) else None
+        if rp_ms:
+            out["roofline"]["frac_rocprof"] = round(flops / (rp_ms * 1e-3) / 1e12 / peak, 4)
+            out["roofline"]["rocprof_kernel_ms_per_step"] = round(rp_ms, 3)
+            out["roofline"]["rocprof_source"] = os.path.relpath(ROCPROF_CSV, REPO) + " (committed profile of an earlier run of this command with --serial; not this run)"
         if lrecs:
             lms = sum(sum(d) for d in lrecs) / len(lrecs)                     # pose_prepare + fused loss kernel + finalize
             lmain = sum(d[1] for d in lrecs) / len(lrecs)
@@ -337,7 +372,9 @@ def main():
                                     "ms": round(lms, 4), "main_kernel_ms": round(lmain, 4),
                                     "note": "achieved = 52 B/pixel over the three launches of the loss stage (per-dispatch HIP events); traffic = PMC bytes of the main kernel"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(H, W, args.depth_layers, args.ssim)
+        # SURVEY.md 8d asks for 3 warm-up + 10 timed steps: taken when the run itself is the full-length one (--steps >= 100, the default)
+        full = args.steps >= 100
+        out["cpu_baseline"] = cpu_baseline(H, W, args.depth_layers, args.ssim, warm=3 if full else 1, steps=10 if full else 5)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

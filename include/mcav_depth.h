@@ -61,6 +61,17 @@ int mcav_warp_loss_fwd_bwd(const float* tgt, const float* ref0, const float* ref
                            float* losses, float* d_disp_t, float* d_disp_r0, float* d_poses,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* DIAGNOSTIC twin of mcav_warp_loss_fwd_bwd (upstream (1,1)): the same kernel bodies with a per-pixel dump, used by
+ * tests/flip_finder.py to NAME the pixels at which an fp32 evaluation takes another bilinear cell / L1 sign than float64 does
+ * (losses.py:183-240 is only piecewise smooth).  taps: [B][3 warps][7][H][W] = { ix, iy (un-normalised sampling position, source pixels),
+ * d loss_mam / d ix, d loss_mam / d iy, residual of channel 0..2 } per warp (0: ref0 -> tgt, 1: ref1 -> tgt, 2: tgt with depth(ref0) and the
+ * inverted pose[0]; with MCAV_WL_SSIM the residual planes are left zero).  Not used by the training path. */
+int mcav_warp_loss_debug_taps(const float* tgt, const float* ref0, const float* ref1,
+                              const float* disp_t, const float* disp_r0, const float* poses, const void* K,
+                              int B, int H, int W, unsigned flags, const float* term_weights,
+                              float* losses, float* d_disp_t, float* d_disp_r0, float* d_poses,
+                              void* workspace, size_t workspace_bytes, float* taps, size_t taps_floats, void* stream);
+
 /* Standalone inverse_warp (pose_geometry.py:201-229): img [B,3,H,W], depth [B,H,W], pose [B,6], K [B,3,3]
  * -> out [B,3,H,W].  flags: MCAV_WL_K_F64.  pose_inv as in the reference. */
 int mcav_inverse_warp_fwd(const float* img, const float* depth, const float* pose, const void* K,

@@ -211,3 +211,64 @@ def test_bf16_train_step_runs_and_tracks_fp32():
         cos = float(F.cosine_similarity(n16[n].flatten(), n32[n].flatten(), dim=0))
         print("bf16 vs fp32 gradient cosine %-45s %.4f" % (n, cos))
         assert cos > 0.9, (n, cos)
+
+
+def test_bf16_whole_step_at_config2_size_is_reproducible_and_tracks_fp32():
+    """BASELINE.json configs[2]'s per-GPU shape as a TEST (round 2 had it only as a bench line): batch 12, 192x640, ResNet-18 on the bf16 MFMA
+    conv tiles + PoseNet, the whole step on the three HIP streams.  Properties that need no oracle at this size: bit-reproducible from the
+    same state (losses, every gradient of the arena, the updated parameters); finite; losses within 5 % of the fp32 step on the same
+    weights and batch; the gradient arena correlated with the fp32 one (cosine > 0.9 overall and on the decoder / layer4 slices)."""
+    from losses import Losses
+    from mcav.optim import FusedAdam
+    from mcav.streams import Branch
+    from models.depth.resnet_dispnet import DispResNet
+    from models.pose.pose_net import PoseNet
+    from oracle.step import synthetic_batch
+    s = synthetic_batch(12, 192, 640, seed=9)
+    tgt, refs, K = s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], s["intrinsics"].to(DEV)
+    out = {}
+    for name, dt in (("fp32", None), ("bf16", torch.bfloat16)):
+        d = reinit_by_name(DispResNet(dtype=dt), 141).to(DEV).train()
+        p = reinit_by_name(PoseNet(), 121).to(DEV).train()
+        with torch.no_grad():
+            p.pose_pred.weight.mul_(0.1)
+            p.pose_pred.bias.mul_(0.1)
+        opt = FusedAdam(list(d.parameters()) + list(p.parameters()), 1e-4)
+        state = {k: v.clone() for k, v in d.state_dict().items()}
+        flat0 = opt.arena().flat.clone()
+        branch, runs = Branch(), []
+        for rep in range(2 if dt is not None else 1):
+            d.load_state_dict(state)
+            with torch.no_grad():
+                opt.arena().flat.copy_(flat0)
+                opt._m.zero_(); opt._v.zero_()
+            opt._step = 0
+            opt.arena().bump()
+            opt.zero_grad()
+            poses = branch.fork(p, tgt, refs)
+            disps = list(d.forward_pair(tgt, refs[0]))
+            poses = branch.join(poses)
+            loss = Losses().forward(tgt, refs, disps, poses, K, None)
+            sum(loss).backward()
+            g = opt.arena().gflat.clone()
+            opt.step()
+            torch.cuda.synchronize()
+            runs.append(([float(l.detach()) for l in loss], g, opt.arena().flat.clone()))
+        out[name] = runs
+        spans = {n: (o, o + q.numel()) for q, o, n in zip(opt.arena().params, opt.arena().offsets,
+                                                          [n for n, _ in list(d.named_parameters()) + list(p.named_parameters())])}
+        del d, p, opt
+    (l16, g16, f16), (l16b, g16b, f16b) = out["bf16"]
+    (l32, g32, _), = out["fp32"]
+    assert l16 == l16b and torch.equal(g16, g16b) and torch.equal(f16, f16b)
+    assert torch.isfinite(g16).all() and torch.isfinite(f16).all() and float(g16.abs().max()) > 0
+    for a, b in zip(l16, l32):
+        assert abs(a - b) < 5e-2 * abs(b), (l16, l32)
+    cos = lambda a, b: float(F.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0))
+    print("bf16 vs fp32 at 12x192x640: losses %s / %s, arena gradient cosine %.4f" % (l16, l32, cos(g16, g32)))
+    assert cos(g16, g32) > 0.9
+    for n in ("encoder.encoder.layer4.1.conv2.weight", "decoder.decoder.0.conv.conv.weight", "decoder.decoder.7.conv.conv.weight"):
+        lo, hi = spans[n]
+        c = cos(g16[lo:hi], g32[lo:hi])
+        print("   %-45s %.4f" % (n, c))
+        assert c > 0.9, (n, c)

@@ -82,7 +82,27 @@ def _worker_overlap(rank, world, port, out):
         N.grads_ready(params[2:4])                         # overlaps ranges already in flight: ignored
         scale = mdist.allreduce_gradients(a)
         results.append(a.gflat.tolist())
-    out.put((rank, results, scale))
+    gs = mdist._SYNC[id(a)]
+    buckets = list(gs.last_buckets)
+    # the remainder in collectives of at most 32 bytes (MCAV_DP_BUCKET_MB): same sums, more collectives
+    os.environ["MCAV_DP_BUCKET_MB"] = str(32.0 / (1 << 20))
+    g = torch.Generator().manual_seed(5000 + rank)
+    a.gflat.copy_(torch.randn(a.numel, generator=g))
+    N.grads_ready(params[3:5])
+    mdist.allreduce_gradients(a)
+    results.append(a.gflat.tolist())
+    small = list(gs.last_buckets)
+    # bench.py's self-validation: equal parameters pass, a rank that drifted by one ulp in one element is caught
+    agree = mdist.check_ranks_agree(a, [torch.tensor(float(rank))])
+    caught = False
+    if rank == 1:
+        with torch.no_grad():
+            a.flat[3] = torch.nextafter(a.flat[3], torch.tensor(float("inf")))
+    try:
+        mdist.check_ranks_agree(a)
+    except RuntimeError:
+        caught = True
+    out.put((rank, results, scale, buckets, small, agree, caught))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -98,13 +118,29 @@ def test_two_rank_bucketed_overlap_equals_one_allreduce():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, r0, s0), (_, r1, s1) = res
+    (_, r0, s0, b0, sm0, ag0, c0), (_, r1, s1, b1, sm1, ag1, c1) = res
     assert s0 == s1 == 0.5
     numel = len(r0[0])
-    for step in range(2):
-        want = sum(torch.randn(numel, generator=torch.Generator().manual_seed(1000 * step + r)) for r in range(2))
+    for step, seed in ((0, 0), (1, 1000), (2, 5000)):
+        want = sum(torch.randn(numel, generator=torch.Generator().manual_seed(seed + r)) for r in range(2))
         assert r0[step] == r1[step]
         assert torch.equal(torch.tensor(r0[step]), want)           # every element summed exactly once
+    assert b0 == b1 and len(b0) == 4 and sum(b0) == 4 * numel     # two announced buckets + the two remainder ranges around them
+    assert sm0 == sm1 and max(sm0[1:]) <= 32 and sum(sm0) == 4 * numel and len(sm0) > len(b0)
+    assert ag0["parameters_equal_across_ranks"] and ag0["ranks"] == 2 and ag0["loss_per_rank"] == [[0.0], [1.0]] and ag0 == ag1
+    assert c0 and c1                                               # the one-ulp drift of rank 1 raised on BOTH ranks
+
+
+def test_announced_stage_knob(monkeypatch):
+    from mcav import dist as mdist
+    monkeypatch.delenv("MCAV_DP_BUCKETS", raising=False)
+    assert mdist.announced_stages() == {"decoder", "layer4"}
+    monkeypatch.setenv("MCAV_DP_BUCKETS", "none")
+    assert mdist.announced_stages() == frozenset()
+    monkeypatch.setenv("MCAV_DP_BUCKETS", "decoder, layer4,layer3")
+    assert mdist.announced_stages() == {"decoder", "layer4", "layer3"}
+    monkeypatch.setenv("MCAV_DP_BUCKET_MB", "16")
+    assert mdist.remainder_bucket_elems() == 4 << 20
 
 
 def test_gradsync_buckets_on_the_real_networks():

@@ -12,11 +12,26 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def build_pair(seed_d=141, seed_p=121, layers=18):
+def damp_residual_branches(net, gamma3):
+    """The last BatchNorm of every Bottleneck gets its gamma scaled by gamma3 (the standard "zero-init residual" idea, not all the way to
+    zero so that every convolution of the branch keeps a gradient): the residual branches add a fifth of a unit of variance each instead of
+    a whole one, which is the regime trained ResNet-50s live in.  At the seeding's gamma ~ 1 the 16 stacked train-mode BatchNorm branches
+    amplify a 1e-6 perturbation into 3e-2 of layer3 / layer4's gradients in float64 (tests/arbiter.py envelope); damped, the CPU fp32 oracle
+    sits within 8e-4 of float64 on every tensor (median 3e-6), so an absolute bound on the HIP path means something."""
+    with torch.no_grad():
+        for n, m in net.named_modules():
+            if n.endswith("bn3"):
+                m.weight.mul_(gamma3)
+    return net
+
+
+def build_pair(seed_d=141, seed_p=121, layers=18, gamma3=None):
     from models.depth.resnet_dispnet import DispResNet
     from models.pose.pose_net import PoseNet
     from oracle import nets as on
     hip_d, hip_p = reinit_by_name(DispResNet(layers), seed_d), reinit_by_name(PoseNet(), seed_p)
+    if gamma3 is not None:
+        damp_residual_branches(hip_d, gamma3)
     ref_d, ref_p = on.DispResNet(layers), on.PoseNet()
     ref_d.load_state_dict(hip_d.state_dict())        # same names and shapes: the state_dict is interchangeable
     ref_p.load_state_dict(hip_p.state_dict())
@@ -30,17 +45,20 @@ def build_pair(seed_d=141, seed_p=121, layers=18):
 # the last two cases are BASELINE.json configs[3]'s combination (ResNet-50 encoder + the fused warp + SSIM loss) as ONE step
 @pytest.mark.parametrize("B,H,W,pair,ssim,layers", [(2, 64, 128, False, False, 18), (3, 96, 160, False, False, 18), (2, 64, 128, True, False, 18),
                                                      (3, 96, 160, True, False, 18), (2, 64, 128, True, True, 18),
-                                                     (4, 64, 128, True, True, 50), (2, 128, 192, True, True, 50)])
+                                                     (4, 64, 128, True, True, 50), (2, 128, 192, True, True, 50),
+                                                     # ResNet-50 where the problem is well conditioned (damped residual branches, batch 8): the
+                                                     # absolute 2e-3 bound of the ResNet-18 cases applies
+                                                     (8, 96, 160, True, False, -50)])
 def test_train_step_vs_oracle(B, H, W, pair, ssim, layers):
+    damped = layers < 0
+    layers = abs(layers)
     from losses import Losses
     from mcav.optim import FusedAdam
     from oracle.step import make_optimizer, synthetic_batch, train_step
-    hip_d, hip_p, ref_d, ref_p = build_pair(layers=layers)
+    hip_d, hip_p, ref_d, ref_p = build_pair(layers=layers, gamma3=0.2 if damped else None)
     s = synthetic_batch(B, H, W, seed=5)
     from arbiter import Verdicts, double_copy, to_double
     d64, p64 = double_copy(ref_d), double_copy(ref_p)          # the float64 arbiter: same weights, same code, before the update
-    import copy as _copy
-    ref_d_before, ref_p_before = _copy.deepcopy(ref_d), _copy.deepcopy(ref_p)      # fp32 copies for the perturbed fp32 oracle steps
     ropt = make_optimizer(ref_d, ref_p, 1e-4)
     (rdisps, rposes), rloss = train_step(ref_d, ref_p, ropt, s, ssim_weight=0.85 if ssim else 0.0)
 
@@ -75,17 +93,25 @@ def test_train_step_vs_oracle(B, H, W, pair, ssim, layers):
         de, pe = perturb_(double_copy(d64), 1e-6, 300 + e), perturb_(double_copy(p64), 1e-6, 400 + e)
         se = dict(s64, tgt=perturb_tensor(s64["tgt"], 1e-6, 500 + e), ref_imgs=[perturb_tensor(r, 1e-6, 600 + 10 * e + i) for i, r in enumerate(s64["ref_imgs"])])
         envs.append(step64(de, pe, se)[2])
-    # ... and the selection flips: dL/dposes moves in discrete steps when one pixel's L1 sign / SSIM clamp / in-view test changes side
-    # (tools/flip_probe.py on MI355X, this step's SSIM case: the HIP kernel and the CPU fp32 oracle on IDENTICAL inputs sit 1.2e-3 and
-    # 2.2e-5 from float64; inputs perturbed by 1e-6..1e-5 put HIP at 2.0e-4 or 1.2e-3 and the CPU fp32 oracle at 3e-5, 1.2e-3 or 1.5e-3,
-    # while float64 itself moves by 6e-5 at most).  Which side an fp32 evaluation lands on is decided by its rounding, so the envelope
-    # also holds the CPU fp32 oracle's step on inputs and weights perturbed by 1e-5 (three draws; one for ResNet-50).
-    import copy
-    for e in range(3 if layers == 18 else 1):
-        de, pe = perturb_(copy.deepcopy(ref_d_before), 1e-5, 700 + e), perturb_(copy.deepcopy(ref_p_before), 1e-5, 800 + e)
-        se = dict(s, tgt=perturb_tensor(s["tgt"], 1e-5, 900 + e), ref_imgs=[perturb_tensor(r, 1e-5, 950 + 10 * e + i) for i, r in enumerate(s["ref_imgs"])])
-        envs.append(step64(de, pe, se)[2])
+    # Selection flips: dL/dposes moves in discrete steps when ONE pixel's bilinear cell / L1 sign / SSIM clamp is decided the other way, and a
+    # pixel within rounding of such a kink is decided by the rounding of whichever fp32 evaluation looks at it (tests/flip_finder.py;
+    # test_loss_gpu.py::test_hip_pose_gradient_gaps_are_named_tie_pixels names them on this very case).  Round 2 widened the envelope by the
+    # CPU fp32 oracle's step on 1e-5-perturbed inputs; that is gone.  Instead the HIP loss kernel's per-pixel dump is diffed against float64
+    # on IDENTICAL inputs, every pixel decided differently must be a named tie (float64 margin at rounding level), and the float64 reference
+    # of the tensors downstream of the poses -- PoseNet's parameters, nothing else -- takes the same side at exactly those pixels.
+    import flip_finder as ff
+    taps, _, _ = ff.hip_taps(tgt, refs, disps[0][0].detach().contiguous(), disps[1][0].detach().contiguous(), poses.detach().contiguous(), K, ssim=ssim)
+    hip_inputs = (s["tgt"], s["ref_imgs"], disps[0][0].detach().cpu(), disps[1][0].detach().cpu(), poses.detach().cpu())
+    delta, flips, untied = ff.flip_correction(hip_inputs, taps, s["intrinsics"], 0.85 if ssim else 0.0)
+    print("pixels the HIP loss kernel decides differently from float64: %s" % [(f["b"], f["warp"], f["y"], f["x"], f["kind"], "%.1e" % f["margin"]) for f in flips])
+    assert not untied, "decided differently from float64 without a tie: %s" % untied
     disps64, poses64, g64 = step64(d64, p64, s64)
+    n_depth = len(list(d64.parameters()))
+    if flips:      # float64 PoseNet gradients with the named pixels on the HIP kernel's side: g + (d poses / d theta)^T delta
+        pp = p64(s64["tgt"], s64["ref_imgs"])
+        pparams = [q for q in p64.parameters()]
+        extra = torch.autograd.grad(pp, pparams, grad_outputs=delta, allow_unused=True)
+        g64 = list(g64[:n_depth]) + [g if e is None else g + e for g, e in zip(g64[n_depth:], extra)]
     v = Verdicts(floor=2.5e-4)
     v.add("disp(tgt)", disps[0][0], rdisps[0][0], disps64[0][0])
     v.add("poses", poses, rposes, poses64)
@@ -97,9 +123,10 @@ def test_train_step_vs_oracle(B, H, W, pair, ssim, layers):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
         v.add(n, p.grad, q.grad, g64[i], [env[i] for env in envs])
-    v.check("test_train_step_vs_oracle[%d-%d-%d-%s-%s-R%d]" % (B, H, W, pair, ssim, layers), hip_abs=2e-3 if layers == 18 else None)
-    # (ResNet-50 at random init and these batch sizes is ill-conditioned -- the 1e-6 perturbation alone moves layer3/4 gradients by 3e-2 in
-    #  float64 -- so it gets the relative rule only; every tensor's row is printed above)
+    v.check("test_train_step_vs_oracle[%d-%d-%d-%s-%s-R%d%s]" % (B, H, W, pair, ssim, layers, "-damped" if damped else ""),
+            hip_abs=2e-3 if (layers == 18 or damped) else None)
+    # (ResNet-50 at the seeding's gamma ~ 1 and batch 2-4 is ill-conditioned -- the 1e-6 perturbation alone moves layer3/4 gradients by 3e-2
+    #  in float64 -- so those two cases get the relative rule only; the damped batch-8 case carries the absolute bound)
     # optimiser parity after the update
     opt.step()
     torch.cuda.synchronize()

@@ -2074,14 +2074,16 @@ MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t wor
     if (pl.groups) {
         float* pre = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pl.slab_bytes);
         const size_t elems = (size_t)(pl.p.Ktot + 1) * pl.p.slabN;
-        wgrad_presum_kernel<<<dim3((unsigned)((elems / 4 + 255) / 256), pl.groups), 256, 0, s>>>(pl.p.slab, pl.p.splits, elems, pl.per_group, pre);
+        // (timed with the GEMM: the weight gradient is not finished until the slab is reduced -- bench.py's wgrad stage counts both)
+        timed_launch(wgrad_presum_kernel, dim3((unsigned)((elems / 4 + 255) / 256), pl.groups), dim3(256), 0, s, (const float*)pl.p.slab, pl.p.splits, elems,
+                     pl.per_group, pre);
         rsrc = pre;
         rsplits = pl.groups;
     }
     const int cin_total = d->Cin_total > 0 ? d->Cin_total : d->Cin;
     if (d->ci_offset < 0 || d->ci_offset + d->Cin > cin_total) return MCAV_E_INVALID;
-    wgrad_reduce_kernel<<<rgrid, 256, lds_bytes, s>>>(rsrc, rsplits, pl.p.Ktot, pl.p.slabN, pl.p.Kp, out_taps, d->Cout, d->Cin, pl.ci_t,
-                                                     d->dw_oihw, d->dbias, d->accumulate, pl.p.upm, cin_total, d->ci_offset);
+    timed_launch(wgrad_reduce_kernel, rgrid, dim3(256), lds_bytes, s, rsrc, rsplits, pl.p.Ktot, pl.p.slabN, pl.p.Kp, out_taps, d->Cout, d->Cin, pl.ci_t,
+                 d->dw_oihw, d->dbias, d->accumulate, pl.p.upm, cin_total, d->ci_offset);
     return launch_status();
 }
 

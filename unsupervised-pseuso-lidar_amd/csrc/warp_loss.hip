@@ -33,7 +33,9 @@ struct WLArgs {
     int B, H, W;
     unsigned flags;
     float tw[3];
+    float* dbg;          // test-only instantiation (mcav_warp_loss_debug_taps): [B][3 warps][WL_DBG planes][H][W]
 };
+constexpr int WL_DBG = 7;      // ix, iy, d loss / d ix, d loss / d iy, res[0..2]
 
 __device__ __forceinline__ void load_K(const void* K, bool f64, int b, double* Kd) {
     if (f64) {
@@ -128,6 +130,7 @@ __device__ __forceinline__ void gather_taps(__amdgpu_buffer_rsrc_t rs, const Tap
         for (int k = 0; k < 4; ++k) q[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)f.o[k], c * plane_bytes, 0));
 }
 
+template <bool DBG>
 __global__ __launch_bounds__(256) void warp_loss_kernel(WLArgs a) {
     const float g0 = a.upstream[0], g1 = a.upstream[1];
     if ((a.flags & MCAV_WL_SKIP_IF_UNIT) && g0 == 1.0f && g1 == 1.0f) return;
@@ -204,9 +207,16 @@ __global__ __launch_bounds__(256) void warp_loss_kernel(WLArgs a) {
             gather_taps(rs_r0, tap_offsets(t0, W), pb, q0);
             gather_taps(rs_r1, tap_offsets(t1, W), pb, q1);
             gather_taps(rs_t, tap_offsets(t2, W), pb, q2);
-            warp_pixel_from(q0, tvv, pc.sc.w[0].P, r, t0, H, W, a.tw[0] * invN, g0 * a.tw[0] * invN, acc[0], dDt, acc + 2);
-            warp_pixel_from(q1, tvv, pc.sc.w[1].P, r, t1, H, W, a.tw[1] * invN, g0 * a.tw[1] * invN, acc[0], dDt, acc + 14);
-            warp_pixel_from(q2, rvv, pc.sc.w[2].P, r, t2, H, W, a.tw[2] * invN, g0 * a.tw[2] * invN, acc[0], dDr, acc + 26);
+            float dbg[DBG ? 3 : 1][WL_DBG];
+            warp_pixel_from(q0, tvv, pc.sc.w[0].P, r, t0, H, W, a.tw[0] * invN, g0 * a.tw[0] * invN, acc[0], dDt, acc + 2, DBG ? dbg[0] : nullptr);
+            warp_pixel_from(q1, tvv, pc.sc.w[1].P, r, t1, H, W, a.tw[1] * invN, g0 * a.tw[1] * invN, acc[0], dDt, acc + 14, DBG ? dbg[DBG ? 1 : 0] : nullptr);
+            warp_pixel_from(q2, rvv, pc.sc.w[2].P, r, t2, H, W, a.tw[2] * invN, g0 * a.tw[2] * invN, acc[0], dDr, acc + 26, DBG ? dbg[DBG ? 2 : 0] : nullptr);
+            if constexpr (DBG) {
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+#pragma unroll
+                    for (int k = 0; k < WL_DBG; ++k) a.dbg[(((size_t)b * 3 + w) * WL_DBG + k) * plane + pix] = dbg[w][k];
+            }
             if (!(a.flags & MCAV_WL_NO_SMOOTH)) {
                 float gs = 0.f, ls = 0.f;
                 smooth_terms_sel([&](int dy, int dx) { return sD[cy + dy][cx + dx]; }, x, y, H, W, cxx, cyy, cxy, ls, gs);
@@ -257,6 +267,7 @@ __device__ __forceinline__ SsimPoint ssim_point(const float* x, const float* y) 
     return o;
 }
 
+template <bool DBG>
 __global__ __launch_bounds__(256) void warp_loss_ssim_kernel(WLArgs a) {
     const float g0 = a.upstream[0], g1 = a.upstream[1];
     if ((a.flags & MCAV_WL_SKIP_IF_UNIT) && g0 == 1.0f && g1 == 1.0f) return;
@@ -418,6 +429,11 @@ __global__ __launch_bounds__(256) void warp_loss_ssim_kernel(WLArgs a) {
             }
             const float d = backproject_grad(P, r, t, gix, giy, H, W, acc + 2 + 12 * w);
             if (w < 2) dDt[sub] += d; else dDr[sub] += d;
+            if constexpr (DBG) {      // (the residual planes of the dump stay zero: the mix's value-level kinks are judged on the oracle's margins)
+                const float v[WL_DBG] = {t.ix, t.iy, gix, giy, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < WL_DBG; ++k) a.dbg[(((size_t)b * 3 + w) * WL_DBG + k) * plane + (size_t)y * W + x] = v[k];
+            }
         }
     }
 
@@ -740,10 +756,10 @@ MCAV_EXPORT size_t mcav_warp_loss_workspace_bytes(int B, int H, int W) {
     return ws_layout(B, H, W).total;
 }
 
-MCAV_EXPORT int mcav_warp_loss_fwd_bwd(const float* tgt, const float* ref0, const float* ref1, const float* disp_t, const float* disp_r0,
-                                       const float* poses, const void* K, int B, int H, int W, unsigned flags, const float* upstream,
-                                       const float* term_weights, float* losses, float* d_disp_t, float* d_disp_r0, float* d_poses,
-                                       void* workspace, size_t workspace_bytes, void* stream) {
+static int warp_loss_launch(const float* tgt, const float* ref0, const float* ref1, const float* disp_t, const float* disp_r0,
+                            const float* poses, const void* K, int B, int H, int W, unsigned flags, const float* upstream,
+                            const float* term_weights, float* losses, float* d_disp_t, float* d_disp_r0, float* d_poses,
+                            void* workspace, size_t workspace_bytes, void* stream, float* dbg) {
     if (!tgt || !ref0 || !ref1 || !disp_t || !disp_r0 || !poses || !K || !losses || !d_disp_t || !d_disp_r0 || !d_poses || !workspace)
         return MCAV_E_INVALID;
     if (B <= 0 || H < 3 || W < 3 || B > 65535) return MCAV_E_INVALID;
@@ -764,12 +780,35 @@ MCAV_EXPORT int mcav_warp_loss_fwd_bwd(const float* tgt, const float* ref0, cons
     a.tw[0] = term_weights ? term_weights[0] : 0.25f;
     a.tw[1] = term_weights ? term_weights[1] : 0.25f;
     a.tw[2] = term_weights ? term_weights[2] : 0.5f;
+    a.dbg = dbg;
     const dim3 wl_grid((W + TW - 1) / TW, (H + WLH - 1) / WLH, B);
-    if (flags & MCAV_WL_SSIM) timed_launch(warp_loss_ssim_kernel, wl_grid, dim3(256), 0, s, a);
-    else timed_launch(warp_loss_kernel, wl_grid, dim3(256), 0, s, a);
+    if (flags & MCAV_WL_SSIM) {
+        if (dbg) timed_launch(warp_loss_ssim_kernel<true>, wl_grid, dim3(256), 0, s, a);
+        else timed_launch(warp_loss_ssim_kernel<false>, wl_grid, dim3(256), 0, s, a);
+    } else if (dbg) timed_launch(warp_loss_kernel<true>, wl_grid, dim3(256), 0, s, a);
+    else timed_launch(warp_loss_kernel<false>, wl_grid, dim3(256), 0, s, a);
     timed_launch(warp_loss_finalize_kernel, dim3(B), dim3(1024), 0, s, (const float*)slab, (int)(wl_grid.x * wl_grid.y), (const PrepConst*)pc, poses, up, flags,
                  d_poses, sl, reinterpret_cast<unsigned*>(ones) + 2, B, losses);
     return launch_status();
+}
+
+MCAV_EXPORT int mcav_warp_loss_fwd_bwd(const float* tgt, const float* ref0, const float* ref1, const float* disp_t, const float* disp_r0,
+                                       const float* poses, const void* K, int B, int H, int W, unsigned flags, const float* upstream,
+                                       const float* term_weights, float* losses, float* d_disp_t, float* d_disp_r0, float* d_poses,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    return warp_loss_launch(tgt, ref0, ref1, disp_t, disp_r0, poses, K, B, H, W, flags, upstream, term_weights, losses, d_disp_t, d_disp_r0, d_poses,
+                            workspace, workspace_bytes, stream, nullptr);
+}
+
+// Diagnostic twin of mcav_warp_loss_fwd_bwd: the same kernel bodies instantiated with their per-pixel dump on.
+MCAV_EXPORT int mcav_warp_loss_debug_taps(const float* tgt, const float* ref0, const float* ref1, const float* disp_t, const float* disp_r0,
+                                          const float* poses, const void* K, int B, int H, int W, unsigned flags, const float* term_weights,
+                                          float* losses, float* d_disp_t, float* d_disp_r0, float* d_poses, void* workspace,
+                                          size_t workspace_bytes, float* taps, size_t taps_floats, void* stream) {
+    if (!taps || (flags & MCAV_WL_SKIP_IF_UNIT) || B <= 0 || H <= 0 || W <= 0) return MCAV_E_INVALID;
+    if (taps_floats < (size_t)B * 3 * WL_DBG * H * W) return MCAV_E_WORKSPACE;
+    return warp_loss_launch(tgt, ref0, ref1, disp_t, disp_r0, poses, K, B, H, W, flags, nullptr, term_weights, losses, d_disp_t, d_disp_r0, d_poses,
+                            workspace, workspace_bytes, stream, taps);
 }
 
 MCAV_EXPORT int mcav_inverse_warp_fwd(const float* img, const float* depth, const float* pose, const void* K, int B, int H, int W, int pose_inv,

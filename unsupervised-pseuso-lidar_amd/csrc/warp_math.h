@@ -217,8 +217,10 @@ MCAV_HD void smooth_terms_sel(F DD, int x, int y, int H, int W, float cxx, float
 // lw: weight of |res| in the loss; gw: weight of sign(res) in the gradient (= upstream * lw).
 // The same with the 3 x 4 texels already fetched (q[c][0..3] = nw, ne, sw, se of channel c): the fused kernel issues the gathers of all
 // three warps of a pixel before it consumes any (csrc/warp_loss.hip).
+// dbg (test builds of the kernel only, tests/flip_finder.py): receives {ix, iy, d loss / d ix, d loss / d iy, res[0..2]} of this warp at
+// this pixel -- the per-pixel quantities the fp64 oracle is diffed against to NAME a pixel whose cell / L1 sign an fp32 evaluation flips.
 MCAV_HD void warp_pixel_from(const float (*q)[4], const float* tv, const float* P, const Ray& r, const Tap& t, int H, int W,
-                             float lw, float gw, float& loss, float& dD, float* dP) {
+                             float lw, float gw, float& loss, float& dD, float* dP, float* dbg = nullptr) {
     float gix = 0.f, giy = 0.f;
     for (int c = 0; c < 3; ++c) {
         const Sample s = bilinear_from(q[c][0], q[c][1], q[c][2], q[c][3], t);
@@ -227,7 +229,9 @@ MCAV_HD void warp_pixel_from(const float (*q)[4], const float* tv, const float* 
         const float sg = sgn(res) * gw;
         gix += sg * s.dvdx;
         giy += sg * s.dvdy;
+        if (dbg) dbg[4 + c] = res;
     }
+    if (dbg) { dbg[0] = t.ix; dbg[1] = t.iy; dbg[2] = gix; dbg[3] = giy; }
     dD += backproject_grad(P, r, t, gix, giy, H, W, dP);
 }
 

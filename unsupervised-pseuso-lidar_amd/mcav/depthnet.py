@@ -144,8 +144,10 @@ def encoder_backward(net, sv, dfeats, complete=False):
             addend = dfeats[si] if (bi == 0 and si > 0) else None      # skip-connection gradient of this stage's input
             bwd = bottleneck_backward if hasattr(blks[bi], "conv3") else block_backward
             dcur = bwd(blks[bi], sv["blocks"][si][bi], dcur, addend)
-        if complete and si == 3:       # layer4 holds half of all parameters and finishes first: its all-reduce hides behind layers 3..1
-            N.grads_ready(getattr(net, STAGES[si]).parameters())
+        if complete and N.GRADS_READY is not None:       # layer4 holds half of all parameters and finishes first: its all-reduce hides behind layers 3..1
+            from .dist import announced_stages
+            if STAGES[si] in announced_stages():
+                N.grads_ready(getattr(net, STAGES[si]).parameters())
     # dcur = gradient w.r.t. the max-pool output; f0 also feeds the decoder
     df0 = N.maxpool_bwd(dcur, sv["idx"], tuple(feats[0].shape), dx=dfeats[0], accumulate=True)
     dc1 = N.bn_backward(net.bn1, sv["st"], df0, feats[0], sv["c1"], True)

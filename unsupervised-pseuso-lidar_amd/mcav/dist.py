@@ -42,6 +42,20 @@ def broadcast_parameters(arena, src=0):
         arena.bump()
 
 
+def announced_stages():
+    """MCAV_DP_BUCKETS: which parameter groups a backward pass announces as final (each becomes one asynchronous bucket of the all-reduce,
+    in this order of completion): any of decoder, layer4, layer3, layer2, layer1; "none" = one collective after backward.  Default
+    "decoder,layer4" -- 70 % of the arena's bytes with half of the backward still to run (xGMI sizing in DESIGN.md section 7)."""
+    v = os.environ.get("MCAV_DP_BUCKETS", "decoder,layer4").strip().lower()
+    return frozenset() if v in ("", "none", "0") else frozenset(t.strip() for t in v.split(","))
+
+
+def remainder_bucket_elems():
+    """MCAV_DP_BUCKET_MB: the part of the arena no announcement covered goes out in collectives of at most this many MiB (0 = one)."""
+    mb = float(os.environ.get("MCAV_DP_BUCKET_MB", "0") or 0)
+    return int(mb * (1 << 20) / 4) if mb > 0 else 0
+
+
 class GradSync:
     """The gradient all-reduce, overlapped with backward in a few contiguous buckets of the flat arena.
 
@@ -91,10 +105,13 @@ class GradSync:
         """Call after backward() has returned (all streams joined).  Reduces the remaining ranges, then waits for all."""
         if world() > 1:
             pos = 0
+            step = remainder_bucket_elems()
             for lo, hi in sorted(self.done) + [(self.arena.numel, self.arena.numel)]:
-                if lo > pos:
-                    self.works.append(dist.all_reduce(self.arena.gflat[pos:lo], op=dist.ReduceOp.SUM, async_op=True))
-                    self.sizes.append(4 * (lo - pos))
+                while lo > pos:
+                    end = min(lo, pos + step) if step else lo
+                    self.works.append(dist.all_reduce(self.arena.gflat[pos:end], op=dist.ReduceOp.SUM, async_op=True))
+                    self.sizes.append(4 * (end - pos))
+                    pos = end
                 pos = max(pos, hi)
             for w in self.works:
                 w.wait()
@@ -133,3 +150,23 @@ def shard_indices(indices, r=None, w=None):
     w = world() if w is None else w
     per = len(indices) // w
     return indices[r * per:(r + 1) * per]
+
+
+def check_ranks_agree(arena, loss=None):
+    """After a run: every rank must hold the SAME parameters (same seed, same all-reduced gradients, same Adam update).  All-gathers two
+    float64 checksums of the parameter arena (sum, sum of |.|) and the last losses; raises when a rank differs in a single bit of either
+    checksum.  -> dict for the bench line.  One rank: trivially true."""
+    flat = arena.flat.detach()
+    mine = torch.stack([flat.double().sum(), flat.double().abs().sum()] + [l.detach().double().reshape(()) for l in (loss or [])]).reshape(1, -1)
+    w = world()
+    if w == 1:
+        return {"ranks": 1, "parameters_equal_across_ranks": True, "parameter_checksum": [float(mine[0, 0]), float(mine[0, 1])]}
+    allv = [torch.zeros_like(mine) for _ in range(w)]
+    dist.all_gather(allv, mine)
+    allv = torch.cat(allv, 0).cpu()
+    equal = bool((allv[:, :2] == allv[0:1, :2]).all())
+    out = {"ranks": w, "parameters_equal_across_ranks": equal, "parameter_checksum": [float(allv[0, 0]), float(allv[0, 1])],
+           "loss_per_rank": [[round(float(x), 6) for x in row[2:]] for row in allv]}
+    if not equal:
+        raise RuntimeError("data-parallel ranks hold different parameters after the run: checksums %s" % allv[:, :2].tolist())
+    return out

@@ -27,6 +27,7 @@ _SIGNATURES = {
     "mcav_abi_version": (c_i, []),
     "mcav_warp_loss_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "mcav_warp_loss_fwd_bwd": (c_i, [c_p] * 7 + [c_i, c_i, c_i, c_u, c_p, c_p] + [c_p] * 4 + [c_p, c_sz, c_p]),
+    "mcav_warp_loss_debug_taps": (c_i, [c_p] * 7 + [c_i, c_i, c_i, c_u, c_p] + [c_p] * 4 + [c_p, c_sz, c_p, c_sz, c_p]),
     "mcav_inverse_warp_fwd": (c_i, [c_p] * 4 + [c_i, c_i, c_i, c_i, c_u, c_p, c_p, c_sz, c_p]),
     "mcav_inverse_warp_bwd": (c_i, [c_p] * 5 + [c_i, c_i, c_i, c_i, c_u, c_p, c_p, c_p, c_sz, c_p]),
     "mcav_reconstruct": (c_i, [c_p, c_p, c_i, c_i, c_i, c_u, c_p, c_p, c_sz, c_p]),

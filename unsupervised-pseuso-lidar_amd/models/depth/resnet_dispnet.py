@@ -231,7 +231,10 @@ class _DispResNetPairFn(torch.autograd.Function):
             gb = torch.zeros_like(ref) if gb is None else gb
         g = torch.cat([L.dev(ga.contiguous(), "grad"), L.dev(gb.contiguous(), "grad")], 0)
         dfe = E.decoder_backward(mod.decoder, ctx.dsv, {0: g.view(g.shape[0], g.shape[2], g.shape[3], 1)})
-        N.grads_ready(mod.decoder.parameters())        # both passes are in this one backward: the decoder's gradients are final
+        if N.GRADS_READY is not None:                   # both passes are in this one backward: the decoder's gradients are final
+            from mcav.dist import announced_stages
+            if "decoder" in announced_stages():
+                N.grads_ready(mod.decoder.parameters())
         E.encoder_backward(mod.encoder.encoder, ctx.esv, dfe, complete=True)
         ctx.esv = ctx.dsv = None
         return (None, None, None) + (None,) * len(list(mod.parameters()))
