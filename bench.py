@@ -326,7 +326,7 @@ def main():
             with open(args.layer_report, "w") as f:
                 for (kind, fl, ms1), tag in zip(recs[2 * n1:], tags[2 * n1:]):
                     f.write("%-6s %-58s %8.2f GF %8.3f ms %7.2f TF/s\n" % (kind, tag, fl / 1e9, ms1, fl / (ms1 * 1e-3) / 1e12))
-        lrecs = [durs[i0:i1] for (_, i0, i1) in N.PROFILE_LOSS if i1 - i0 == 3]
+        lrecs = [durs[i0:i1] for (_, i0, i1) in N.PROFILE_LOSS if i1 - i0 == 1]      # the forward call's ONE launch (the backward's re-run is a device-side no-op)
         N.PROFILE_LOSS = None
         ms = sum(t for (_, _, t) in recs) / 3.0
         flops = sum(f for (_, f, _) in recs) / 3.0
@@ -363,14 +363,14 @@ def main():
             out["roofline"]["rocprof_kernel_ms_per_step"] = round(rp_ms, 3)
             out["roofline"]["rocprof_source"] = os.path.relpath(ROCPROF_CSV, REPO) + " (committed profile of an earlier run of this command with --serial; not this run)"
         if lrecs:
-            lms = sum(sum(d) for d in lrecs) / len(lrecs)                     # pose_prepare + fused loss kernel + finalize
-            lmain = sum(d[1] for d in lrecs) / len(lrecs)
+            lms = sum(sum(d) for d in lrecs) / len(lrecs)                     # the fused kernel (per-sample constants and the finalize are inside it)
+            lmain = lms
             lbytes = 52.0 * B * H * W
             out["roofline_warp"] = {"bound": "hbm", "achieved": round(lbytes / (lms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": round(lbytes / (lms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": warp_traffic,
-                                    "kernel": "%s (+prepare/finalize), 52 B/pixel x %d pixels" % ("warp_loss_ssim_kernel" if args.ssim else "warp_loss_kernel", B * H * W),
+                                    "kernel": "%s (one launch: per-sample constants, warp + loss forward/backward, finalize), 52 B/pixel x %d pixels" % ("warp_loss_ssim_kernel" if args.ssim else "warp_loss_l1_kernel", B * H * W),
                                     "ms": round(lms, 4), "main_kernel_ms": round(lmain, 4),
-                                    "note": "achieved = 52 B/pixel over the three launches of the loss stage (per-dispatch HIP events); traffic = PMC bytes of the main kernel"}
+                                    "note": "achieved = 52 B/pixel over the loss stage's one launch (per-dispatch HIP events); traffic = PMC bytes of the kernel"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # SURVEY.md 8d asks for 3 warm-up + 10 timed steps: taken when the run itself is the full-length one (--steps >= 100, the default)
         full = args.steps >= 100

@@ -47,6 +47,9 @@ int mcav_abi_version(void);
 #define MCAV_WL_INPUT_DEPTH 8u    /* disp_t / disp_r0 already hold depths; gradients are w.r.t. depth */
 #define MCAV_WL_SSIM 16u          /* photometric term = 0.85 * SSIM distance + 0.15 * L1 (reference losses.py:12-54, weights of :77) instead of L1 */
 
+/* The workspace holds per-workgroup partial sums and the completion tickets of the fused kernel (since round 3 the per-sample constants and
+ * the float64 finalize run INSIDE it: one launch).  It must be ZERO-FILLED before its first use; every launch leaves the tickets at zero, so
+ * one buffer serves all later calls on the same stream.  One launch at a time per workspace. */
 size_t mcav_warp_loss_workspace_bytes(int B, int H, int W);
 
 /* tgt, ref0, ref1: [B,3,H,W].  disp_t, disp_r0: [B,1,H,W] sigmoid disparities of tgt and ref0 (scale 0).

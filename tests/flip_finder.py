@@ -79,7 +79,7 @@ def hip_taps(tgt, refs, disp_t, disp_r, poses, K, ssim=False):
     B, _, H, W = tgt.shape
     dev = tgt.device
     h = L.lib()
-    ws = L.workspace(h.mcav_warp_loss_workspace_bytes(B, H, W), dev, "warp_loss")
+    ws = L.workspace(h.mcav_warp_loss_workspace_bytes(B, H, W), dev, "warp_loss", zero=True)
     taps = torch.zeros(B, 3, NPLANES, H, W, dtype=torch.float32, device=dev)
     losses = torch.empty(2, dtype=torch.float32, device=dev)
     g_dt, g_dr, g_p = torch.empty_like(disp_t), torch.empty_like(disp_r), torch.empty_like(poses)

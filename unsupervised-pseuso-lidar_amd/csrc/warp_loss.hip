@@ -26,11 +26,14 @@ struct PrepConst {
 
 struct WLArgs {
     const float *tgt, *ref0, *ref1, *disp_t, *disp_r0, *poses;
-    const float* upstream;
-    float *d_disp_t, *d_disp_r0;
-    const PrepConst* pc;
-    float* slab;
+    const void* K;                 // [B,3,3] fp64 (MCAV_WL_K_F64) or fp32
+    const float* upstream;         // 2 floats on the device, or nullptr = (1, 1)
+    float *d_disp_t, *d_disp_r0, *d_poses, *losses;
+    float* slab;                   // [B][nblk][SLAB] per-workgroup partial sums
+    double* sample_loss;           // [B][2]
+    unsigned* tickets;             // [B + 1], zero between launches: workgroups done per sample; samples done
     int B, H, W;
+    int G0, G1;                    // L1 kernel: workgroups per sample of pass 0 (warps 0, 1 + smoothness) / pass 1 (warp 2)
     unsigned flags;
     float tw[3];
     float* dbg;          // test-only instantiation (mcav_warp_loss_debug_taps): [B][3 warps][WL_DBG planes][H][W]
@@ -107,8 +110,15 @@ __device__ __forceinline__ void block_reduce_store(float* acc, float* dst, float
 // warps are issued back to back behind one counted wait (the predicated form compiled to ~90 exec-masked regions, each with its own wait).
 constexpr unsigned WL_OOB = 0x80000000u;
 
+// (the base is wave-uniform by construction; said explicitly, because a 64-bit sample offset formed on the vector ALU made the compiler
+//  treat the descriptor as divergent and wrap every gather in a waterfall loop)
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const float* img, size_t plane) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, (unsigned)(3 * plane * sizeof(float)), 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(img)), 0, (unsigned)(3 * plane * sizeof(float)), 0x00020000);
 }
 
 struct TapOff { unsigned o[4]; };
@@ -130,106 +140,345 @@ __device__ __forceinline__ void gather_taps(__amdgpu_buffer_rsrc_t rs, const Tap
         for (int k = 0; k < 4; ++k) q[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)f.o[k], c * plane_bytes, 0));
 }
 
-template <bool DBG>
-__global__ __launch_bounds__(256) void warp_loss_kernel(WLArgs a) {
-    const float g0 = a.upstream[0], g1 = a.upstream[1];
-    if ((a.flags & MCAV_WL_SKIP_IF_UNIT) && g0 == 1.0f && g1 == 1.0f) return;
-    __shared__ float sD[WL_LH][LW + 1];
-    __shared__ float sred[4][SLAB];
-    const int H = a.H, W = a.W, b = blockIdx.z;
-    const int bx0 = blockIdx.x * TW, by0 = blockIdx.y * WLH;
-    const size_t plane = (size_t)H * W;
-    const bool in_depth = (a.flags & MCAV_WL_INPUT_DEPTH) != 0;
-    const float* dt = a.disp_t + (size_t)b * plane;
-    for (int i = threadIdx.x; i < WL_LH * LW; i += 256) {
-        const int ly = i / LW, lx = i - ly * LW;
-        const int gy = by0 - HALO + ly, gx = bx0 - HALO + lx;
-        float D = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const float v = dt[(size_t)gy * W + gx];
-            D = in_depth ? v : 1.0f / (10.0f * v + 0.01f);
-        }
-        sD[ly][lx] = D;
+// ---------------------------------------------------------------------------------------------- one launch: prologue and epilogue of the fused kernels
+// Round 3 folds the two helper launches into the fused kernels (they were 13 of the loss stage's 83 us):
+//   * prologue: every workgroup derives its sample's constants itself (lanes 0..2: Rodrigues, P = K [R|t], Q = P[:, :3] K^-1 for one warp each;
+//     float64 inverse of K) into LDS, and every wavefront lifts them into scalar registers;
+//   * epilogue: per-workgroup partial sums go to the slab; a per-sample ticket names the LAST workgroup of a sample, which sums that sample's
+//     slab entries in float64 (fixed order: bit-reproducible), turns dP into the pose gradients and emits the sample's loss sums; a second
+//     ticket names the last SAMPLE, which adds the samples up in index order.  Tickets are left at zero for the next launch.
+struct alignas(16) SampleFast {
+    WarpFast w[3];       // 12 floats each
+    float Kinv[12];      // 9 used
+};
+
+// Twelve wave-uniform floats from LDS as three 16-byte broadcast reads, NOT hoisted out of the pixel loop (volatile): held in registers for
+// the whole loop the three warps' constants cost 45 registers -- as scalars they overflowed the scalar file and the buffer resources with them.
+struct F12 { float v[12]; };
+__device__ __forceinline__ F12 lds12(const float* p) {
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    // LDS byte address of p (the low 32 bits of a generic pointer into LDS are its LDS offset); ds_read_b128 through inline asm keeps the
+    // loads where they are written -- three per use, nothing held across the loop
+    const unsigned addr = (unsigned)reinterpret_cast<unsigned long long>(p);
+    F12 r;
+    f4 t0, t1, t2;
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2) : "v"(addr) : "memory");
+    r.v[0] = t0.x; r.v[1] = t0.y; r.v[2] = t0.z; r.v[3] = t0.w;
+    r.v[4] = t1.x; r.v[5] = t1.y; r.v[6] = t1.z; r.v[7] = t1.w;
+    r.v[8] = t2.x; r.v[9] = t2.y; r.v[10] = t2.z; r.v[11] = t2.w;
+    return r;
+}
+__device__ __forceinline__ WarpFast lds_warp(const WarpFast& w) {
+    const F12 r = lds12(w.Q);
+    WarpFast u;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) u.Q[i] = r.v[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u.p3[i] = r.v[9 + i];
+    return u;
+}
+
+__device__ __forceinline__ void block_prepare(const WLArgs& a, int b, SampleFast* sf) {
+    if (threadIdx.x < 3) {
+        const int w = threadIdx.x;
+        double Kd[9], Ki[9];
+        load_K(a.K, (a.flags & MCAV_WL_K_F64) != 0, b, Kd);
+        invert3x3(Kd, Ki);
+        float Kf[9], Kinv[9], R[9], t[3], P[12];
+        for (int i = 0; i < 9; ++i) { Kf[i] = (float)Kd[i]; Kinv[i] = (float)Ki[i]; }
+        pose_to_Rt(a.poses + (size_t)b * 12 + (w == 1 ? 6 : 0), w == 2, R, t);
+        make_P(Kf, R, t, P);
+        make_fast(P, Kinv, sf->w[w]);
+        if (w == 0)
+            for (int i = 0; i < 9; ++i) sf->Kinv[i] = Kinv[i];
     }
     __syncthreads();
+}
 
-    const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;
-    const int x = bx0 + tx;
-    float acc[NACC];
+__device__ __forceinline__ float uniform_of(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ WarpFast uniform_warp(const WarpFast& w) {
+    WarpFast u;
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    for (int i = 0; i < 9; ++i) u.Q[i] = uniform_of(w.Q[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u.p3[i] = uniform_of(w.p3[i]);
+    return u;
+}
 
-    const PrepConst& pc = a.pc[b];
-    const float* tgt = a.tgt + (size_t)b * 3 * plane;
-    const float* ref0 = a.ref0 + (size_t)b * 3 * plane;
-    const float* ref1 = a.ref1 + (size_t)b * 3 * plane;
-    const int pb = (int)(plane * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rs_t = image_rsrc(tgt, plane), rs_r0 = image_rsrc(ref0, plane), rs_r1 = image_rsrc(ref1, plane);
-    const __amdgpu_buffer_rsrc_t rs_dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.disp_r0 + (size_t)b * plane), 0, (unsigned)pb, 0x00020000);
-    const float invN = 1.0f / (float)((size_t)a.B * 3 * plane);
-    const float cxx = 1.0f / (float)((size_t)a.B * H * (W - 2));
-    const float cyy = 1.0f / (float)((size_t)a.B * (H - 2) * W);
-    const float cxy = 2.0f / (float)((size_t)a.B * (H - 1) * (W - 1));   // dxdy and dydx are the same field
-    // the target-aligned values of a pixel (3 tgt, 3 ref1, 1 disparity) are fetched ONE PIXEL AHEAD, branch-free (a pixel outside the image
-    // reads zeros through the out-of-range offset and is skipped), so their flight overlaps the previous pixel's arithmetic
-    auto fetch = [&](int sub, float (&v)[7]) {      // v = tgt[0..2], ref1[0..2], disparity of ref0
-        const int y = by0 + sub * TH + ty0;
-        const unsigned off = (x < W && y < H) ? (unsigned)((y * W + x) * 4) : WL_OOB;
+constexpr int RED_LD = 256 + 8;      // one pad float per 32 threads: the transposed reads are conflict-free
+
+// Sum N per-thread values over the 256 threads (fixed order) into out[slot(k)]: each value's 256 addends are written to LDS, 8 lanes
+// take 32 of them each, three xor-shuffles finish.  ~N + 50 instructions per thread instead of 12 N for N wavefront butterflies.
+template <int N, class Slot>
+__device__ __forceinline__ void block_sum_to_slab(const float* acc, float (*sred)[RED_LD], float* out, Slot slot) {
+    const int tid = threadIdx.x;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            v[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_t, (int)off, c * pb, 0));
-            v[3 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r1, (int)off, c * pb, 0));
+    for (int k = 0; k < N; ++k) sred[k][tid + (tid >> 5)] = acc[k];
+    __syncthreads();
+    const int k = tid >> 3, part = tid & 7;
+    float s = 0.f;
+    if (k < N) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) s += sred[k][part * 33 + j];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (k < N && part == 0) out[slot(k)] = s;
+}
+
+// after the workgroup's slab entry is written: ticket, and the last workgroup of the sample finishes the sample
+__device__ __forceinline__ void block_finish(const WLArgs& a, int b, int nblk, double (*s64)[SLAB], int* s_flag) {
+    const int tid = threadIdx.x;
+    __threadfence();                                             // this workgroup's slab entry is visible device-wide ...
+    __syncthreads();
+    if (tid == 0) *s_flag = atomicAdd(&a.tickets[b], 1u) == (unsigned)(nblk - 1);      // ... before its ticket is
+    __syncthreads();
+    if (!*s_flag) return;
+    __threadfence();
+    const float* slab = a.slab + (size_t)b * nblk * SLAB;
+    constexpr int PARTS = 256 / SLAB;                            // 6 x 40 = 240 threads
+    if (tid < PARTS * SLAB) {
+        const int part = tid / SLAB, k = tid - part * SLAB;
+        double sum = 0.0;
+        for (int blk = part; blk < nblk; blk += PARTS)
+            sum += (double)__hip_atomic_load(slab + (size_t)blk * SLAB + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // written by other workgroups
+        s64[part][k] = sum;
+    }
+    __syncthreads();
+    if (tid < SLAB) {
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < PARTS; ++p) t += s64[p][tid];
+        s64[0][tid] = t;
+    }
+    __syncthreads();
+    if (tid < 3) {                                               // one warp's pose gradient per lane
+        double Kd[9];
+        load_K(a.K, (a.flags & MCAV_WL_K_F64) != 0, b, Kd);
+        float Kf[9];
+        for (int i = 0; i < 9; ++i) Kf[i] = (float)Kd[i];
+        double g[6];
+        pose_grad_from_dP(&s64[0][2 + 12 * tid], Kf, a.poses + (size_t)b * 12 + (tid == 1 ? 6 : 0), tid == 2, g);
+        for (int i = 0; i < 6; ++i) s64[1 + tid][i] = g[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 0; i < 6; ++i) {
+            a.d_poses[(size_t)b * 12 + i] = (float)(s64[1][i] + s64[3][i]);      // pose[0]: warp 0 and (through its inverse) warp 2
+            a.d_poses[(size_t)b * 12 + 6 + i] = (float)s64[2][i];
         }
-        v[6] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dr, (int)off, 0, 0));
-    };
-    float pv[WL_SUB][7];
-    fetch(0, pv[0]);
-#pragma unroll
-    for (int sub = 0; sub < WL_SUB; ++sub) {
-        const int ty = sub * TH + ty0, y = by0 + ty;
-        if (sub + 1 < WL_SUB) fetch(sub + 1, pv[sub + 1]);
-        const float tvv[3] = {pv[sub][0], pv[sub][1], pv[sub][2]}, rvv[3] = {pv[sub][3], pv[sub][4], pv[sub][5]};
-        const float vr = pv[sub][6];
-        if (x < W && y < H) {
-            const size_t pix = (size_t)y * W + x;
-            const int cy = ty + HALO, cx = tx + HALO;
-            const float Dt = sD[cy][cx];
-            const float Dr = in_depth ? vr : 1.0f / (10.0f * vr + 0.01f);
-            const Ray r = pixel_ray(pc.sc.Kinv, (float)x, (float)y);
-            float dDt = 0.f, dDr = 0.f;
-            // the three projections first, then all 36 gathers, then the arithmetic (same operations in the same order as warp_pixel)
-            // warp 0: ref0 -> tgt view, depth(tgt), pose[0];  warp 1: ref1 -> tgt view, depth(tgt), pose[1];
-            // warp 2: tgt -> "ref1 view", depth(ref0), inverse(pose[0])   (reference quirk, losses.py:203-207)
-            const Tap t0 = project_pixel(pc.sc.w[0].P, r, Dt, H, W);
-            const Tap t1 = project_pixel(pc.sc.w[1].P, r, Dt, H, W);
-            const Tap t2 = project_pixel(pc.sc.w[2].P, r, Dr, H, W);
-            float q0[3][4], q1[3][4], q2[3][4];
-            gather_taps(rs_r0, tap_offsets(t0, W), pb, q0);
-            gather_taps(rs_r1, tap_offsets(t1, W), pb, q1);
-            gather_taps(rs_t, tap_offsets(t2, W), pb, q2);
-            float dbg[DBG ? 3 : 1][WL_DBG];
-            warp_pixel_from(q0, tvv, pc.sc.w[0].P, r, t0, H, W, a.tw[0] * invN, g0 * a.tw[0] * invN, acc[0], dDt, acc + 2, DBG ? dbg[0] : nullptr);
-            warp_pixel_from(q1, tvv, pc.sc.w[1].P, r, t1, H, W, a.tw[1] * invN, g0 * a.tw[1] * invN, acc[0], dDt, acc + 14, DBG ? dbg[DBG ? 1 : 0] : nullptr);
-            warp_pixel_from(q2, rvv, pc.sc.w[2].P, r, t2, H, W, a.tw[2] * invN, g0 * a.tw[2] * invN, acc[0], dDr, acc + 26, DBG ? dbg[DBG ? 2 : 0] : nullptr);
-            if constexpr (DBG) {
-#pragma unroll
-                for (int w = 0; w < 3; ++w)
-#pragma unroll
-                    for (int k = 0; k < WL_DBG; ++k) a.dbg[(((size_t)b * 3 + w) * WL_DBG + k) * plane + pix] = dbg[w][k];
+        a.sample_loss[b * 2 + 0] = s64[0][0];
+        a.sample_loss[b * 2 + 1] = s64[0][1];
+        a.tickets[b] = 0;
+        __threadfence();
+        if (atomicAdd(&a.tickets[a.B], 1u) == (unsigned)(a.B - 1)) {
+            __threadfence();
+            double l0 = 0.0, l1 = 0.0;
+            for (int i = 0; i < a.B; ++i) {
+                l0 += __hip_atomic_load(a.sample_loss + i * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                l1 += __hip_atomic_load(a.sample_loss + i * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (!(a.flags & MCAV_WL_NO_SMOOTH)) {
-                float gs = 0.f, ls = 0.f;
-                smooth_terms_sel([&](int dy, int dx) { return sD[cy + dy][cx + dx]; }, x, y, H, W, cxx, cyy, cxy, ls, gs);
-                acc[1] += ls;
-                dDt += g1 * gs;
-            }
-            a.d_disp_t[(size_t)b * plane + pix] = in_depth ? dDt : dDt * (-10.0f * Dt * Dt);
-            a.d_disp_r0[(size_t)b * plane + pix] = in_depth ? dDr : dDr * (-10.0f * Dr * Dr);
+            a.losses[0] = (float)l0;
+            a.losses[1] = (float)l1;
+            a.tickets[a.B] = 0;
         }
     }
-    const int nblk = gridDim.x * gridDim.y;
-    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-    block_reduce_store<NACC>(acc, a.slab + ((size_t)b * nblk + blk) * SLAB, sred);
+}
+
+// ---------------------------------------------------------------------------------------------- fused warp + L1 + smoothness (round 3)
+// The kernel is bound by instruction issue, not by HBM (52 B/pixel against ~1100 vector instructions per pixel in round 2).  What changed:
+//   * the per-pixel arithmetic (csrc/warp_math.h, "lean forms"): affine q, reciprocals, nested lerp -- about 500 instructions per pixel;
+//   * ONE warp at a time: a workgroup of pass 0 runs warps 0 and 1 (both use depth(tgt) and the target's pixels) and the smoothness term,
+//     a workgroup of pass 1 runs warp 2 (depth(ref0)): 26 / 13 running sums instead of 38, <= 128 registers, four wavefronts per SIMD;
+//   * the 12 gathers of a warp are issued one unit AHEAD of their use (two register sets: pass 0 alternates the two warps of a pixel,
+//     pass 1 the two pixels a thread owns in a tile), the target-aligned values one pixel ahead of that;
+//   * a workgroup walks tiles g, g + G, ... of one sample (32 x 16 pixels, two per thread) and reduces its sums ONCE, through LDS;
+//   * no helper launches (see above).
+constexpr int T2H = 16, T2LH = T2H + 2 * HALO;
+constexpr int RED_N0 = 26, RED_N1 = 13;
+
+template <bool DBG>
+__global__ __launch_bounds__(256, 3) void warp_loss_l1_kernel(WLArgs a) {
+    float g0 = 1.0f, g1 = 1.0f;
+    if (a.upstream) {
+        g0 = a.upstream[0];
+        g1 = a.upstream[1];
+        if ((a.flags & MCAV_WL_SKIP_IF_UNIT) && g0 == 1.0f && g1 == 1.0f) return;
+    }
+    __shared__ SampleFast s_sf;
+    __shared__ float sD[T2LH][LW + 1];
+    __shared__ __attribute__((aligned(16))) float sred[RED_N0][RED_LD];
+    __shared__ int s_flag;
+    const int H = a.H, W = a.W, b = blockIdx.y, tid = threadIdx.x;
+    const bool pass1 = (int)blockIdx.x >= a.G0;
+    const int g = pass1 ? (int)blockIdx.x - a.G0 : (int)blockIdx.x, G = pass1 ? a.G1 : a.G0;
+    const int ntx = (W + TW - 1) / TW, nty = (H + T2H - 1) / T2H, ntiles = ntx * nty;
+    const int nmine = (ntiles - g + G - 1) / G;                  // tiles g, g + G, ... of this sample (the host keeps G <= ntiles)
+    const float inv_ntx = 1.0f / (float)ntx;
+    block_prepare(a, b, &s_sf);
+
+    // Scalar-register budget: only the GATHERED images are buffer resources (a tap outside the image = an out-of-range offset that reads
+    // zero); the pixel-aligned reads and the gradient stores are plain global accesses under the pixel's in-image predicate.  With all seven
+    // tensors as resources plus three warps' constants the descriptors spilled into vector registers and every load became a waterfall loop.
+    const size_t plane = (size_t)H * W;
+    const int pb = (int)(plane * sizeof(float));
+    const bool in_depth = (a.flags & MCAV_WL_INPUT_DEPTH) != 0;
+    const float invN = 1.0f / (float)((size_t)a.B * 3 * plane);
+    const int tx = tid & 31, ty0 = tid >> 5;
+
+    // j-th pixel of this thread: tile j >> 1 of the workgroup's list, upper / lower half of its 16 rows
+    auto pixel = [&](int j, int& x, int& y, unsigned& off) {
+        const int t = g + (j >> 1) * G;
+        const int tyi = (int)(((float)t + 0.5f) * inv_ntx), txi = t - tyi * ntx;
+        x = txi * TW + tx;
+        y = tyi * T2H + (j & 1) * TH + ty0;
+        off = ((j >> 1) < nmine && x < W && y < H) ? (unsigned)((y * W + x) * 4) : WL_OOB;
+    };
+    auto depth_of = [&](float v) { return in_depth ? v : rcp_nr(fmaf(10.0f, v, 0.01f)); };
+    struct Set { FTap t; float q[3][4]; };
+    auto issue = [&](const WarpFast& wlds, __amdgpu_buffer_rsrc_t src, int x, int y, float D, bool live, Set& s) {
+        s.t = project_fast(lds_warp(wlds), (float)x, (float)y, D, H, W, live);
+        TapOff f;
+        const int base = (s.t.y0 * W + s.t.x0) * 4;
+        f.o[0] = s.t.in00 ? (unsigned)base : WL_OOB;
+        f.o[1] = s.t.in01 ? (unsigned)(base + 4) : WL_OOB;
+        f.o[2] = s.t.in10 ? (unsigned)(base + W * 4) : WL_OOB;
+        f.o[3] = s.t.in11 ? (unsigned)(base + W * 4 + 4) : WL_OOB;
+        gather_taps(src, f, pb, s.q);
+    };
+    auto camera_point = [&](int x, int y, float D, float* X) {
+        const F12 k = lds12(s_sf.Kinv);
+        const float fx = (float)x, fy = (float)y;
+        X[0] = fmaf(k.v[0], fx, fmaf(k.v[1], fy, k.v[2])) * D;
+        X[1] = fmaf(k.v[3], fx, fmaf(k.v[4], fy, k.v[5])) * D;
+        X[2] = fmaf(k.v[6], fx, fmaf(k.v[7], fy, k.v[8])) * D;
+    };
+    auto dump = [&](int w, unsigned off, const float* v) {
+        if (off == WL_OOB) return;
+#pragma unroll
+        for (int k = 0; k < WL_DBG; ++k) a.dbg[(((size_t)b * 3 + w) * WL_DBG + k) * plane + (off >> 2)] = v[k];
+    };
+    float acc[RED_N0];
+#pragma unroll
+    for (int k = 0; k < RED_N0; ++k) acc[k] = 0.f;
+    const int npix = 2 * nmine;
+    float* const slab = a.slab + ((size_t)b * (a.G0 + a.G1) + blockIdx.x) * SLAB;
+
+    if (!pass1) {
+        // ---- pass 0: warps 0 (ref0 -> tgt) and 1 (ref1 -> tgt) with depth(tgt); the smoothness term; d loss / d disp(tgt)
+        const float gw0 = g0 * a.tw[0] * invN, gw1 = g0 * a.tw[1] * invN, lw0 = a.tw[0] * invN, lw1 = a.tw[1] * invN;
+        const float cxx = 1.0f / (float)((size_t)a.B * H * (W - 2));
+        const float cyy = 1.0f / (float)((size_t)a.B * (H - 2) * W);
+        const float cxy = 2.0f / (float)((size_t)a.B * (H - 1) * (W - 1));   // dxdy and dydx are the same field
+        const bool smooth = !(a.flags & MCAV_WL_NO_SMOOTH);
+        const WarpFast &w0 = s_sf.w[0], &w1 = s_sf.w[1];
+        const __amdgpu_buffer_rsrc_t rs_r0 = image_rsrc(a.ref0 + (size_t)b * 3 * plane, plane), rs_r1 = image_rsrc(a.ref1 + (size_t)b * 3 * plane, plane);
+        const float* const dtp = a.disp_t + (size_t)b * plane;
+        const float* const tgp = a.tgt + (size_t)b * 3 * plane;
+        float* const gtp = a.d_disp_t + (size_t)b * plane;
+        auto fetch = [&](unsigned off, float (&v)[4]) {          // disparity and the target's three channels at a pixel (zeros past the image)
+            v[0] = v[1] = v[2] = v[3] = 0.f;
+            if (off != WL_OOB) {
+                const unsigned i = off >> 2;
+                v[0] = dtp[i];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[1 + c] = tgp[c * plane + i];
+            }
+        };
+        int x, y, xn, yn;
+        unsigned off, offn;
+        float cur[4], nxt[4];
+        pixel(0, x, y, off);
+        fetch(off, cur);
+        for (int j = 0; j < npix; ++j) {
+            pixel(j + 1, xn, yn, offn);
+            fetch(offn, nxt);                                    // the next pixel's aligned values fly during this pixel's work
+            const float D = depth_of(cur[0]);
+            float X[3], dDt = 0.f, labs = 0.f, dbg[DBG ? WL_DBG : 1];
+            camera_point(x, y, D, X);
+            Set st;
+            issue(w0, rs_r0, x, y, D, off != WL_OOB, st);
+            warp_unit_fast(st.q, cur + 1, st.t, X, H, W, gw0, labs, dDt, acc + 2, DBG ? dbg : nullptr);
+            acc[0] = fmaf(labs, lw0, acc[0]);
+            if constexpr (DBG) dump(0, off, dbg);
+            issue(w1, rs_r1, x, y, D, off != WL_OOB, st);
+            labs = 0.f;
+            warp_unit_fast(st.q, cur + 1, st.t, X, H, W, gw1, labs, dDt, acc + 14, DBG ? dbg : nullptr);
+            acc[0] = fmaf(labs, lw1, acc[0]);
+            if constexpr (DBG) dump(1, off, dbg);
+            if (smooth) {
+                if (!(j & 1)) {                                  // first pixel of a tile: publish its depth tile (+ 2 halo)
+                    const int by0 = y - ty0, bx0 = x - tx;
+                    __syncthreads();                             // the previous tile's readers are done
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        const int i = tid + 256 * m, ly = i / LW, lx = i - ly * LW;
+                        const int gy = by0 - HALO + ly, gx = bx0 - HALO + lx;
+                        if (i < T2LH * LW) sD[ly][lx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? depth_of(dtp[gy * W + gx]) : 0.f;
+                    }
+                    __syncthreads();
+                }
+                if (off != WL_OOB) {
+                    const int cy = (j & 1) * TH + ty0 + HALO, cx = tx + HALO;
+                    float gs = 0.f, ls = 0.f;
+                    smooth_terms_sel([&](int dy, int dx) { return sD[cy + dy][cx + dx]; }, x, y, H, W, cxx, cyy, cxy, ls, gs);
+                    acc[1] += ls;
+                    dDt = fmaf(g1, gs, dDt);
+                }
+            }
+            if (off != WL_OOB) gtp[off >> 2] = in_depth ? dDt : dDt * (-10.0f * D * D);
+            x = xn; y = yn; off = offn;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+        }
+        __syncthreads();                                         // (sD and sred do not alias, but every wavefront must be out of the loop's barriers)
+        block_sum_to_slab<RED_N0>(acc, sred, slab, [](int k) { return k; });
+        if (tid >= RED_N0 && tid < SLAB) slab[tid] = 0.f;        // warp 2's slots
+    } else {
+        // ---- pass 1: warp 2 (tgt sampled with depth(ref0) and the inverted pose[0], compared with ref1: losses.py:203-207); d loss / d disp(ref0)
+        const float gw2 = g0 * a.tw[2] * invN, lw2 = a.tw[2] * invN;
+        const WarpFast& w2 = s_sf.w[2];
+        const __amdgpu_buffer_rsrc_t rs_t = image_rsrc(a.tgt + (size_t)b * 3 * plane, plane);
+        const float* const drp = a.disp_r0 + (size_t)b * plane;
+        const float* const r1p = a.ref1 + (size_t)b * 3 * plane;
+        float* const grp = a.d_disp_r0 + (size_t)b * plane;
+        auto fetch = [&](unsigned off, float (&v)[4]) {          // disparity of ref0 and ref1's three channels at a pixel (zeros past the image)
+            v[0] = v[1] = v[2] = v[3] = 0.f;
+            if (off != WL_OOB) {
+                const unsigned i = off >> 2;
+                v[0] = drp[i];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[1 + c] = r1p[c * plane + i];
+            }
+        };
+        int x, y, xn, yn;
+        unsigned off, offn;
+        float cur[4], nxt[4];
+        pixel(0, x, y, off);
+        fetch(off, cur);
+        for (int j = 0; j < npix; ++j) {
+            pixel(j + 1, xn, yn, offn);
+            fetch(offn, nxt);
+            const float D = depth_of(cur[0]);
+            float X[3], dDr = 0.f, labs = 0.f, dbg[DBG ? WL_DBG : 1];
+            camera_point(x, y, D, X);
+            Set st;
+            issue(w2, rs_t, x, y, D, off != WL_OOB, st);
+            warp_unit_fast(st.q, cur + 1, st.t, X, H, W, gw2, labs, dDr, acc + 1, DBG ? dbg : nullptr);
+            acc[0] = fmaf(labs, lw2, acc[0]);
+            if constexpr (DBG) dump(2, off, dbg);
+            if (off != WL_OOB) grp[off >> 2] = in_depth ? dDr : dDr * (-10.0f * D * D);
+            x = xn; y = yn; off = offn;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+        }
+        block_sum_to_slab<RED_N1>(acc, sred, slab, [](int k) { return k == 0 ? 0 : 25 + k; });      // loss share; dP of warp 2 -> slots 26..37
+        if (tid >= 1 && tid < 26) slab[tid] = 0.f;
+        if (tid >= 38 && tid < SLAB) slab[tid] = 0.f;
+    }
+    block_finish(a, b, a.G0 + a.G1, reinterpret_cast<double (*)[SLAB]>(&sred[0][0]), &s_flag);
 }
 
 // ---------------------------------------------------------------------------------------------- SSIM + L1 photometric (MCAV_WL_SSIM)
@@ -269,13 +518,20 @@ __device__ __forceinline__ SsimPoint ssim_point(const float* x, const float* y) 
 
 template <bool DBG>
 __global__ __launch_bounds__(256) void warp_loss_ssim_kernel(WLArgs a) {
-    const float g0 = a.upstream[0], g1 = a.upstream[1];
-    if ((a.flags & MCAV_WL_SKIP_IF_UNIT) && g0 == 1.0f && g1 == 1.0f) return;
+    float g0 = 1.0f, g1 = 1.0f;
+    if (a.upstream) {
+        g0 = a.upstream[0];
+        g1 = a.upstream[1];
+        if ((a.flags & MCAV_WL_SKIP_IF_UNIT) && g0 == 1.0f && g1 == 1.0f) return;
+    }
     __shared__ float sD[WL_LH][LW + 1];
     __shared__ float sX[3][WL_LH][LW + 1];
     __shared__ float sT[3][WL_LH][LW + 1];
     __shared__ float sC[3][SS_P][SS_P + 1];
     __shared__ float sred[4][SLAB];
+    __shared__ SampleFast s_sf;
+    __shared__ double s64[256 / SLAB][SLAB];
+    __shared__ int s_flag;
     const int H = a.H, W = a.W, b = blockIdx.z;
     const int bx0 = blockIdx.x * TW, by0 = blockIdx.y * WLH;
     const size_t plane = (size_t)H * W;
@@ -288,11 +544,11 @@ __global__ __launch_bounds__(256) void warp_loss_ssim_kernel(WLArgs a) {
         float D = 0.f;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
             const float v = dt[(size_t)gy * W + gx];
-            D = in_depth ? v : 1.0f / (10.0f * v + 0.01f);
+            D = in_depth ? v : rcp_nr(fmaf(10.0f, v, 0.01f));
         }
         sD[ly][lx] = D;
     }
-    const PrepConst& pc = a.pc[b];
+    block_prepare(a, b, &s_sf);
     const float* img_t = a.tgt + (size_t)b * 3 * plane;
     const float* img_r0 = a.ref0 + (size_t)b * 3 * plane;
     const float* img_r1 = a.ref1 + (size_t)b * 3 * plane;
@@ -311,7 +567,7 @@ __global__ __launch_bounds__(256) void warp_loss_ssim_kernel(WLArgs a) {
         const int y = by0 + sub * TH + ty0;
         if (x < W && y < H) {
             const float vr = dr[(size_t)y * W + x];
-            Dr[sub] = in_depth ? vr : 1.0f / (10.0f * vr + 0.01f);
+            Dr[sub] = in_depth ? vr : rcp_nr(fmaf(10.0f, vr, 0.01f));
         }
     }
 
@@ -319,7 +575,7 @@ __global__ __launch_bounds__(256) void warp_loss_ssim_kernel(WLArgs a) {
     for (int w = 0; w < 3; ++w) {
         const float* src = w == 0 ? img_r0 : (w == 1 ? img_r1 : img_t);
         const float* tar = w == 2 ? img_r1 : img_t;
-        const float* P = pc.sc.w[w].P;
+        const WarpFast wf = lds_warp(s_sf.w[w]);
         const float lw = a.tw[w] * invN, gw = g0 * lw;
         __syncthreads();                       // sD is filled (w == 0) / the previous warp's readers are done
         // ---- phase 1: warped and target planes on tile + 2 halo
@@ -333,12 +589,15 @@ __global__ __launch_bounds__(256) void warp_loss_ssim_kernel(WLArgs a) {
                 if (w < 2) D = sD[ry - by0 + HALO][rx - bx0 + HALO];
                 else {
                     const float v = dr[(size_t)ry * W + rx];
-                    D = in_depth ? v : 1.0f / (10.0f * v + 0.01f);
+                    D = in_depth ? v : rcp_nr(fmaf(10.0f, v, 0.01f));
                 }
-                const Ray r = pixel_ray(pc.sc.Kinv, (float)rx, (float)ry);
-                const Tap t = project_pixel(P, r, D, H, W);
+                const FTap t = project_fast(wf, (float)rx, (float)ry, D, H, W);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) xv[c] = bilinear(src + c * plane, W, t).v;
+                for (int c = 0; c < 3; ++c) {
+                    float q4[4];
+                    texels_of(src + c * plane, W, t, q4);
+                    xv[c] = bilinear_lerp(q4[0], q4[1], q4[2], q4[3], t.wx1, t.wy1).v;
+                }
                 if (w != 1) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) tv[c] = tar[c * plane + (size_t)ry * W + rx];
@@ -417,17 +676,23 @@ __global__ __launch_bounds__(256) void warp_loss_ssim_kernel(WLArgs a) {
         for (int sub = 0; sub < WL_SUB; ++sub) {
             const int ty = sub * TH + ty0, y = by0 + ty;
             if (!(x < W && y < H)) continue;
-            const Ray r = pixel_ray(pc.sc.Kinv, (float)x, (float)y);
-            const Tap t = project_pixel(P, r, w < 2 ? sD[ty + HALO][tx + HALO] : Dr[sub], H, W);
+            const float Dp = w < 2 ? sD[ty + HALO][tx + HALO] : Dr[sub];
+            const FTap t = project_fast(wf, (float)x, (float)y, Dp, H, W);
             float gix = 0.f, giy = 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const Sample sm = bilinear(src + c * plane, W, t);
+                float q4[4];
+                texels_of(src + c * plane, W, t, q4);
+                const Sample sm = bilinear_lerp(q4[0], q4[1], q4[2], q4[3], t.wx1, t.wy1);
                 const float gv = c == 0 ? gp0[sub] : (c == 1 ? gp1[sub] : gp2[sub]);
                 gix += gv * sm.dvdx;
                 giy += gv * sm.dvdy;
             }
-            const float d = backproject_grad(P, r, t, gix, giy, H, W, acc + 2 + 12 * w);
+            const F12 k = lds12(s_sf.Kinv);
+            const float fx = (float)x, fy = (float)y;
+            const float X[3] = {fmaf(k.v[0], fx, fmaf(k.v[1], fy, k.v[2])) * Dp, fmaf(k.v[3], fx, fmaf(k.v[4], fy, k.v[5])) * Dp,
+                                fmaf(k.v[6], fx, fmaf(k.v[7], fy, k.v[8])) * Dp};
+            const float d = backproject_fast(t, X, gix, giy, H, W, acc + 2 + 12 * w);
             if (w < 2) dDt[sub] += d; else dDr[sub] += d;
             if constexpr (DBG) {      // (the residual planes of the dump stay zero: the mix's value-level kinks are judged on the oracle's margins)
                 const float v[WL_DBG] = {t.ix, t.iy, gix, giy, 0.f, 0.f, 0.f};
@@ -459,59 +724,10 @@ __global__ __launch_bounds__(256) void warp_loss_ssim_kernel(WLArgs a) {
     }
     const int nblk = gridDim.x * gridDim.y;
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-    block_reduce_store<NACC>(acc, a.slab + ((size_t)b * nblk + blk) * SLAB, sred);
-}
-
-// One block per sample: sum the slab in fp64 (26 slices of the tile list per accumulator: short load chains), turn dP into pose
-// gradients, emit per-sample loss sums; the LAST block to finish (ticket in the workspace, zeroed by pose_prepare_kernel) adds the
-// samples up in index order -- one launch less than a separate total kernel, same fixed summation order.
-constexpr int FIN_PARTS = 26;       // 26 x 38 = 988 threads
-
-__global__ __launch_bounds__(1024) void warp_loss_finalize_kernel(const float* slab, int nblk, const PrepConst* pcs, const float* poses,
-                                                                  const float* upstream, unsigned flags, float* d_poses, double* sample_loss,
-                                                                  unsigned* ticket, int B, float* losses) {
-    if ((flags & MCAV_WL_SKIP_IF_UNIT) && upstream[0] == 1.0f && upstream[1] == 1.0f) return;
-    __shared__ double s[FIN_PARTS][NACC];
-    __shared__ bool last;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (tid < FIN_PARTS * NACC) {
-        const int part = tid / NACC, k = tid - part * NACC;
-        double sum = 0.0;
-        for (int blk = part; blk < nblk; blk += FIN_PARTS) sum += (double)slab[((size_t)b * nblk + blk) * SLAB + k];
-        s[part][k] = sum;
-    }
-    __syncthreads();
-    if (tid < NACC) {
-        double t = 0.0;
-        for (int p = 0; p < FIN_PARTS; ++p) t += s[p][tid];
-        s[0][tid] = t;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const PrepConst& pc = pcs[b];
-        const float* p = poses + (size_t)b * 12;
-        double g0[6], g1[6], g2[6];
-        pose_grad_from_dP(&s[0][2], pc.Kf, p, false, g0);
-        pose_grad_from_dP(&s[0][14], pc.Kf, p + 6, false, g1);
-        pose_grad_from_dP(&s[0][26], pc.Kf, p, true, g2);
-        for (int i = 0; i < 6; ++i) {
-            d_poses[(size_t)b * 12 + i] = (float)(g0[i] + g2[i]);
-            d_poses[(size_t)b * 12 + 6 + i] = (float)g1[i];
-        }
-        sample_loss[b * 2 + 0] = s[0][0];
-        sample_loss[b * 2 + 1] = s[0][1];
-        __threadfence();                                        // this sample's sums are visible before the ticket is taken
-        last = atomicAdd(ticket, 1u) == (unsigned)(B - 1);
-        if (last) {
-            __threadfence();
-            double a = 0.0, sm = 0.0;
-            const volatile double* sl = sample_loss;            // written by other workgroups: read from L2
-            for (int i = 0; i < B; ++i) { a += sl[i * 2]; sm += sl[i * 2 + 1]; }
-            losses[0] = (float)a;
-            losses[1] = (float)sm;
-            *ticket = 0;
-        }
-    }
+    float* const slab = a.slab + ((size_t)b * nblk + blk) * SLAB;
+    block_reduce_store<NACC>(acc, slab, sred);
+    if (threadIdx.x >= NACC && threadIdx.x < SLAB) slab[threadIdx.x] = 0.f;
+    block_finish(a, b, nblk, s64, &s_flag);
 }
 
 // ---------------------------------------------------------------------------------------------- standalone warp
@@ -727,20 +943,32 @@ __global__ __launch_bounds__(256) void smooth_finalize_kernel(const float* slab,
 }
 
 struct WsLayout {
-    size_t pc_off, ones_off, slab_off, sl_off, total;
+    size_t pc_off, tick_off, slab_off, sl_off, total;
     int nblk;
 };
 
 inline WsLayout ws_layout(int B, int H, int W) {
     WsLayout l;
-    l.nblk = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    l.nblk = ((W + TW - 1) / TW) * 2 * ((H + T2H - 1) / T2H);      // >= the workgroups per sample of every kernel that writes the slab
     size_t o = 0;
     l.pc_off = o;   o = align_up(o + sizeof(PrepConst) * (size_t)B, 256);
-    l.ones_off = o; o = align_up(o + 16, 256);
+    l.tick_off = o; o = align_up(o + sizeof(unsigned) * ((size_t)B + 1), 256);
     l.slab_off = o; o = align_up(o + sizeof(float) * SLAB * (size_t)B * l.nblk, 256);
     l.sl_off = o;   o = align_up(o + sizeof(double) * 2 * (size_t)B, 256);
     l.total = o;
     return l;
+}
+
+// workgroups per sample of the fused L1 kernel: pass 0 (warps 0, 1 + smoothness: ~2.7 units of work per tile) and pass 1 (warp 2: 1 unit), sized
+// so that every workgroup of the launch is resident at once (256 CUs x 4) and the two kinds take about the same time
+inline void l1_grid(int B, int H, int W, int& G0, int& G1) {
+    const int ntiles = ((W + TW - 1) / TW) * ((H + T2H - 1) / T2H);
+    const int per_sample = 1024 / B > 0 ? 1024 / B : 1;
+    int n0 = (int)((ntiles * 1.37f + per_sample - 1) / per_sample);
+    if (n0 < 1) n0 = 1;
+    const int n1 = (int)(2.7f * n0 + 0.999f);
+    G0 = (ntiles + n0 - 1) / n0;
+    G1 = (ntiles + n1 - 1) / n1;
 }
 
 inline dim3 pix_grid(int B, int H, int W) { return dim3((W + TW - 1) / TW, (H + TH - 1) / TH, B); }
@@ -766,29 +994,28 @@ static int warp_loss_launch(const float* tgt, const float* ref0, const float* re
     const WsLayout l = ws_layout(B, H, W);
     if (workspace_bytes < l.total) return MCAV_E_WORKSPACE;
     char* ws = reinterpret_cast<char*>(workspace);
-    PrepConst* pc = reinterpret_cast<PrepConst*>(ws + l.pc_off);
-    float* ones = reinterpret_cast<float*>(ws + l.ones_off);
-    float* slab = reinterpret_cast<float*>(ws + l.slab_off);
-    double* sl = reinterpret_cast<double*>(ws + l.sl_off);
     hipStream_t s = as_stream(stream);
-    const float* up = upstream ? upstream : ones;
-    timed_launch(pose_prepare_kernel, dim3((B + 63) / 64), dim3(64), 0, s, poses, K, (const float*)nullptr, B, 0, 0, (flags & MCAV_WL_K_F64) ? 1 : 0, pc, ones);
     WLArgs a;
     a.tgt = tgt; a.ref0 = ref0; a.ref1 = ref1; a.disp_t = disp_t; a.disp_r0 = disp_r0; a.poses = poses;
-    a.upstream = up; a.d_disp_t = d_disp_t; a.d_disp_r0 = d_disp_r0; a.pc = pc; a.slab = slab;
-    a.B = B; a.H = H; a.W = W; a.flags = flags;
+    a.K = K; a.upstream = upstream; a.d_disp_t = d_disp_t; a.d_disp_r0 = d_disp_r0; a.d_poses = d_poses; a.losses = losses;
+    a.slab = reinterpret_cast<float*>(ws + l.slab_off);
+    a.sample_loss = reinterpret_cast<double*>(ws + l.sl_off);
+    a.tickets = reinterpret_cast<unsigned*>(ws + l.tick_off);
+    a.B = B; a.H = H; a.W = W; a.flags = flags; a.G0 = 0; a.G1 = 0;
     a.tw[0] = term_weights ? term_weights[0] : 0.25f;
     a.tw[1] = term_weights ? term_weights[1] : 0.25f;
     a.tw[2] = term_weights ? term_weights[2] : 0.5f;
     a.dbg = dbg;
-    const dim3 wl_grid((W + TW - 1) / TW, (H + WLH - 1) / WLH, B);
     if (flags & MCAV_WL_SSIM) {
+        const dim3 wl_grid((W + TW - 1) / TW, (H + WLH - 1) / WLH, B);
         if (dbg) timed_launch(warp_loss_ssim_kernel<true>, wl_grid, dim3(256), 0, s, a);
         else timed_launch(warp_loss_ssim_kernel<false>, wl_grid, dim3(256), 0, s, a);
-    } else if (dbg) timed_launch(warp_loss_kernel<true>, wl_grid, dim3(256), 0, s, a);
-    else timed_launch(warp_loss_kernel<false>, wl_grid, dim3(256), 0, s, a);
-    timed_launch(warp_loss_finalize_kernel, dim3(B), dim3(1024), 0, s, (const float*)slab, (int)(wl_grid.x * wl_grid.y), (const PrepConst*)pc, poses, up, flags,
-                 d_poses, sl, reinterpret_cast<unsigned*>(ones) + 2, B, losses);
+    } else {
+        l1_grid(B, H, W, a.G0, a.G1);
+        const dim3 grid(a.G0 + a.G1, B);
+        if (dbg) timed_launch(warp_loss_l1_kernel<true>, grid, dim3(256), 0, s, a);
+        else timed_launch(warp_loss_l1_kernel<false>, grid, dim3(256), 0, s, a);
+    }
     return launch_status();
 }
 

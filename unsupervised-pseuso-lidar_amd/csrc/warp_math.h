@@ -250,6 +250,131 @@ MCAV_HD void warp_pixel(const float* src, size_t plane, const float* tv, const f
     dD += backproject_grad(P, r, t, gix, giy, H, W, dP);
 }
 
+// ---------------------------------------------------------------------------------------------- the fused kernels' lean forms (round 3)
+// Same quantities as project_pixel / bilinear_from / backproject_grad with a third of the instructions; what changes is rounding, not formulas:
+//   * the camera coordinates c = P [r D; 1] with r = K^-1 [x y 1]^T are evaluated as c_i = D q_i + P_i3, q_i = (P[:, :3] K^-1 [x y 1]^T)_i, and
+//     q_i is affine in the pixel: q_i = Q_i0 x + Q_i1 y + Q_i2 with Q = P[:, :3] K^-1 formed once per (sample, warp) in float64 -- two fmas
+//     per coordinate instead of the reference's r (6), X = r D (3) and P X (12); closer to the exact value than the fp32 chain it replaces;
+//   * divisions become v_rcp_f32 + one Newton step (<= 1 ulp from the correctly rounded quotient) times the numerator;
+//   * the reference's normalise / un-normalise round trip of the sampling position is kept -- (p / (W-1) - 0.5) * 2 and ((g + 1) / 2) * (W-1) --
+//     with its exact scalings by 2 and 1/2 folded into the neighbouring roundings (identical results), the division by W - 1 as a product;
+//   * the bilinear sample is the nested lerp (its x / y derivatives fall out of it), not four weighted texels.
+// Everything is within a few ulp of the reference's fp32 value; tests/hostcheck runs these very functions against the reference goldens.
+struct WarpFast {
+    float Q[9];      // rows of P[:, :3] @ K^-1
+    float p3[3];     // P[:, 3]
+};
+
+MCAV_HD void make_fast(const float* P, const float* Kinv, WarpFast& f) {
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k < 3; ++k)
+            f.Q[i * 3 + k] = (float)((double)P[i * 4 + 0] * (double)Kinv[0 * 3 + k] + (double)P[i * 4 + 1] * (double)Kinv[1 * 3 + k] +
+                                     (double)P[i * 4 + 2] * (double)Kinv[2 * 3 + k]);
+        f.p3[i] = P[i * 4 + 3];
+    }
+}
+
+MCAV_HD float rcp_nr(float z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf(z);
+    return fmaf(r, fmaf(-z, r, 1.0f), r);
+#else
+    return 1.0f / z;
+#endif
+}
+
+struct FTap {
+    float wx1, wy1;            // position inside the bilinear cell
+    float zi, px, py;          // 1 / (z + 1e-5), projected pixel
+    float q0, q1, q2;          // d c / d D
+    float ix, iy;              // sampling position (source pixels)
+    int x0, y0;                // the cell; clamped to [-2, size + 1]
+    bool in00, in01, in10, in11;
+};
+
+// live: false forces every tap out of the image (pixels past the image edge in a ragged tile)
+MCAV_HD FTap project_fast(const WarpFast& f, float x, float y, float D, int H, int W, bool live = true) {
+    FTap t;
+    t.q0 = fmaf(f.Q[0], x, fmaf(f.Q[1], y, f.Q[2]));
+    t.q1 = fmaf(f.Q[3], x, fmaf(f.Q[4], y, f.Q[5]));
+    t.q2 = fmaf(f.Q[6], x, fmaf(f.Q[7], y, f.Q[8]));
+    const float c0 = fmaf(D, t.q0, f.p3[0]), c1 = fmaf(D, t.q1, f.p3[1]), c2 = fmaf(D, t.q2, f.p3[2]);
+    t.zi = rcp_nr(c2 + 1e-5f);
+    t.px = c0 * t.zi;
+    t.py = c1 * t.zi;
+    const float w1 = (float)(W - 1), h1 = (float)(H - 1);
+    const float gx = fmaf(t.px * rcp_nr(w1), 2.0f, -1.0f), gy = fmaf(t.py * rcp_nr(h1), 2.0f, -1.0f);      // (p / (W-1) - 0.5) * 2
+    t.ix = (gx + 1.0f) * (0.5f * w1);                                                                       // ((g + 1) / 2) * (W-1)
+    t.iy = (gy + 1.0f) * (0.5f * h1);
+    // clamp before the conversion (NaN -> -2): beyond [-2, size + 1] no tap is inside the image anyway, and the weights stay finite
+    const float cx = fminf(fmaxf(t.ix, -2.0f), w1 + 2.0f), cy = fminf(fmaxf(t.iy, -2.0f), h1 + 2.0f);
+    const float fx = floorf(cx), fy = floorf(cy);
+    t.wx1 = cx - fx;
+    t.wy1 = cy - fy;
+    t.x0 = (int)fx;
+    t.y0 = (int)fy;
+    const bool xa = (unsigned)t.x0 < (unsigned)W, xb = (unsigned)(t.x0 + 1) < (unsigned)W;
+    const bool ya = live && (unsigned)t.y0 < (unsigned)H, yb = live && (unsigned)(t.y0 + 1) < (unsigned)H;
+    t.in00 = ya && xa; t.in01 = ya && xb; t.in10 = yb && xa; t.in11 = yb && xb;
+    return t;
+}
+
+// value and derivatives w.r.t. (ix, iy) from the four texels (zero outside the image)
+MCAV_HD Sample bilinear_lerp(float nw, float ne, float sw, float se, float wx1, float wy1) {
+    const float t0 = ne - nw, t1 = se - sw;
+    const float top = fmaf(wx1, t0, nw), bot = fmaf(wx1, t1, sw);
+    Sample s;
+    s.dvdy = bot - top;
+    s.v = fmaf(wy1, s.dvdy, top);
+    s.dvdx = fmaf(wy1, t1 - t0, t0);
+    return s;
+}
+
+MCAV_HD float sgn_exact(float v) {      // copysign(1, v), 0 at 0
+    const float s = copysignf(1.0f, v);
+    return v == 0.0f ? 0.0f : s;
+}
+
+// Chain d loss / d (ix, iy) back to the depth and to the 12 entries of P (X = camera point r * D).  Returns d loss / d D.
+MCAV_HD float backproject_fast(const FTap& t, const float* X, float gix, float giy, int H, int W, float* dP) {
+    const float w1 = (float)(W - 1), h1 = (float)(H - 1);
+    const float dpx = (gix * (w1 * 0.5f)) * (2.0f / w1), dpy = (giy * (h1 * 0.5f)) * (2.0f / h1);
+    const float dc0 = dpx * t.zi, dc1 = dpy * t.zi;
+    const float dc2 = -(fmaf(dpx, t.px, dpy * t.py)) * t.zi;
+    dP[0] = fmaf(dc0, X[0], dP[0]); dP[1] = fmaf(dc0, X[1], dP[1]); dP[2] = fmaf(dc0, X[2], dP[2]);   dP[3] += dc0;
+    dP[4] = fmaf(dc1, X[0], dP[4]); dP[5] = fmaf(dc1, X[1], dP[5]); dP[6] = fmaf(dc1, X[2], dP[6]);   dP[7] += dc1;
+    dP[8] = fmaf(dc2, X[0], dP[8]); dP[9] = fmaf(dc2, X[1], dP[9]); dP[10] = fmaf(dc2, X[2], dP[10]); dP[11] += dc2;
+    return fmaf(dc0, t.q0, fmaf(dc1, t.q1, dc2 * t.q2));
+}
+
+// One warp at one pixel from its 3 x 4 texels: sum of |residual| (unweighted), d loss / d depth, the 12 dP sums.
+// gw: weight of sign(res) in the gradient (upstream * term weight / N); X: the camera point r * D; dbg as in warp_pixel_from.
+MCAV_HD void warp_unit_fast(const float (*q)[4], const float* tv, const FTap& t, const float* X, int H, int W, float gw,
+                            float& labs, float& dD, float* dP, float* dbg = nullptr) {
+    float gix = 0.f, giy = 0.f;
+    for (int c = 0; c < 3; ++c) {
+        const Sample s = bilinear_lerp(q[c][0], q[c][1], q[c][2], q[c][3], t.wx1, t.wy1);
+        const float res = s.v - tv[c];
+        labs += fabsf(res);
+        const float sg = sgn_exact(res);
+        gix = fmaf(sg, s.dvdx, gix);
+        giy = fmaf(sg, s.dvdy, giy);
+        if (dbg) dbg[4 + c] = res;
+    }
+    gix *= gw;
+    giy *= gw;
+    if (dbg) { dbg[0] = t.ix; dbg[1] = t.iy; dbg[2] = gix; dbg[3] = giy; }
+    dD += backproject_fast(t, X, gix, giy, H, W, dP);
+}
+
+// the four texels of a tap straight from a plane (standalone / SSIM kernels, host check)
+MCAV_HD void texels_of(const float* plane, int W, const FTap& t, float* q4) {
+    q4[0] = t.in00 ? plane[t.y0 * W + t.x0] : 0.0f;
+    q4[1] = t.in01 ? plane[t.y0 * W + t.x0 + 1] : 0.0f;
+    q4[2] = t.in10 ? plane[(t.y0 + 1) * W + t.x0] : 0.0f;
+    q4[3] = t.in11 ? plane[(t.y0 + 1) * W + t.x0 + 1] : 0.0f;
+}
+
 // d loss / dP (3x4, summed over pixels, fp64) -> d loss / d pose[6], through K, the optional rigid inverse,
 // T = Trans @ Rot and Rodrigues with the +1e-7 guard.  All in fp64.
 MCAV_HD void pose_grad_from_dP(const double* dP, const float* Kf, const float* pose, bool invert, double* dpose) {

@@ -94,11 +94,14 @@ def stream():
 _WS = {}
 
 
-def workspace(nbytes, device, key="default"):
-    """A cached byte workspace per (device, key, stream); grown on demand, reused across calls on that stream."""
+def workspace(nbytes, device, key="default", zero=False):
+    """A cached byte workspace per (device, key, stream); grown on demand, reused across calls on that stream.
+    zero: the buffer is zero-filled when it is (re)allocated -- the fused loss kernels keep their completion tickets in it and leave them at
+    zero after every launch (include/mcav_depth.h: mcav_warp_loss_fwd_bwd)."""
     k = (str(device), key, torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0)   # one per stream: streams overlap
     buf = _WS.get(k)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+        alloc = torch.zeros if zero else torch.empty
+        buf = alloc(max(int(nbytes), 1), dtype=torch.uint8, device=device)
         _WS[k] = buf
     return buf
