@@ -390,22 +390,24 @@ __global__ __launch_bounds__(256, 3) void warp_loss_l1_kernel(WLArgs a) {
         int x, y, xn, yn;
         unsigned off, offn;
         float cur[4], nxt[4];
+        Set s0, s1;
         pixel(0, x, y, off);
         fetch(off, cur);
+        float D = depth_of(cur[0]);
+        issue(w0, rs_r0, x, y, D, off != WL_OOB, s0);
         for (int j = 0; j < npix; ++j) {
             pixel(j + 1, xn, yn, offn);
             fetch(offn, nxt);                                    // the next pixel's aligned values fly during this pixel's work
-            const float D = depth_of(cur[0]);
+            issue(w1, rs_r1, x, y, D, off != WL_OOB, s1);        // warp 1's gathers fly while warp 0 is consumed
             float X[3], dDt = 0.f, labs = 0.f, dbg[DBG ? WL_DBG : 1];
             camera_point(x, y, D, X);
-            Set st;
-            issue(w0, rs_r0, x, y, D, off != WL_OOB, st);
-            warp_unit_fast(st.q, cur + 1, st.t, X, H, W, gw0, labs, dDt, acc + 2, DBG ? dbg : nullptr);
+            warp_unit_fast(s0.q, cur + 1, s0.t, X, H, W, gw0, labs, dDt, acc + 2, DBG ? dbg : nullptr);
             acc[0] = fmaf(labs, lw0, acc[0]);
             if constexpr (DBG) dump(0, off, dbg);
-            issue(w1, rs_r1, x, y, D, off != WL_OOB, st);
+            const float Dn = depth_of(nxt[0]);
+            issue(w0, rs_r0, xn, yn, Dn, offn != WL_OOB, s0);    // the next pixel's warp 0 flies while warp 1 and the smoothness term are worked
             labs = 0.f;
-            warp_unit_fast(st.q, cur + 1, st.t, X, H, W, gw1, labs, dDt, acc + 14, DBG ? dbg : nullptr);
+            warp_unit_fast(s1.q, cur + 1, s1.t, X, H, W, gw1, labs, dDt, acc + 14, DBG ? dbg : nullptr);
             acc[0] = fmaf(labs, lw1, acc[0]);
             if constexpr (DBG) dump(1, off, dbg);
             if (smooth) {
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(256, 3) void warp_loss_l1_kernel(WLArgs a) {
                 }
             }
             if (off != WL_OOB) gtp[off >> 2] = in_depth ? dDt : dDt * (-10.0f * D * D);
-            x = xn; y = yn; off = offn;
+            x = xn; y = yn; off = offn; D = Dn;
 #pragma unroll
             for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
         }
@@ -453,26 +455,39 @@ __global__ __launch_bounds__(256, 3) void warp_loss_l1_kernel(WLArgs a) {
                 for (int c = 0; c < 3; ++c) v[1 + c] = r1p[c * plane + i];
             }
         };
-        int x, y, xn, yn;
-        unsigned off, offn;
-        float cur[4], nxt[4];
-        pixel(0, x, y, off);
-        fetch(off, cur);
-        for (int j = 0; j < npix; ++j) {
-            pixel(j + 1, xn, yn, offn);
-            fetch(offn, nxt);
-            const float D = depth_of(cur[0]);
+        int xa, ya, xb, yb, xna, yna, xnb, ynb;
+        unsigned offa, offb, offna, offnb;
+        float ca[4], cb[4], na[4], nb[4];
+        Set s0, s1;
+        pixel(0, xa, ya, offa);
+        pixel(1, xb, yb, offb);
+        fetch(offa, ca);
+        fetch(offb, cb);
+        float Da = depth_of(ca[0]), Db = depth_of(cb[0]);
+        issue(w2, rs_t, xa, ya, Da, offa != WL_OOB, s0);
+        for (int j = 0; j < npix; j += 2) {
+            pixel(j + 2, xna, yna, offna);
+            pixel(j + 3, xnb, ynb, offnb);
+            fetch(offna, na);
+            fetch(offnb, nb);
+            issue(w2, rs_t, xb, yb, Db, offb != WL_OOB, s1);
             float X[3], dDr = 0.f, labs = 0.f, dbg[DBG ? WL_DBG : 1];
-            camera_point(x, y, D, X);
-            Set st;
-            issue(w2, rs_t, x, y, D, off != WL_OOB, st);
-            warp_unit_fast(st.q, cur + 1, st.t, X, H, W, gw2, labs, dDr, acc + 1, DBG ? dbg : nullptr);
+            camera_point(xa, ya, Da, X);
+            warp_unit_fast(s0.q, ca + 1, s0.t, X, H, W, gw2, labs, dDr, acc + 1, DBG ? dbg : nullptr);
+            if constexpr (DBG) dump(2, offa, dbg);
+            if (offa != WL_OOB) grp[offa >> 2] = in_depth ? dDr : dDr * (-10.0f * Da * Da);
+            const float Dna = depth_of(na[0]), Dnb = depth_of(nb[0]);
+            issue(w2, rs_t, xna, yna, Dna, offna != WL_OOB, s0);
+            dDr = 0.f;
+            camera_point(xb, yb, Db, X);
+            warp_unit_fast(s1.q, cb + 1, s1.t, X, H, W, gw2, labs, dDr, acc + 1, DBG ? dbg : nullptr);
+            if constexpr (DBG) dump(2, offb, dbg);
+            if (offb != WL_OOB) grp[offb >> 2] = in_depth ? dDr : dDr * (-10.0f * Db * Db);
             acc[0] = fmaf(labs, lw2, acc[0]);
-            if constexpr (DBG) dump(2, off, dbg);
-            if (off != WL_OOB) grp[off >> 2] = in_depth ? dDr : dDr * (-10.0f * D * D);
-            x = xn; y = yn; off = offn;
+            xa = xna; ya = yna; offa = offna; Da = Dna;
+            xb = xnb; yb = ynb; offb = offnb; Db = Dnb;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+            for (int k = 0; k < 4; ++k) { ca[k] = na[k]; cb[k] = nb[k]; }
         }
         block_sum_to_slab<RED_N1>(acc, sred, slab, [](int k) { return k == 0 ? 0 : 25 + k; });      // loss share; dP of warp 2 -> slots 26..37
         if (tid >= 1 && tid < 26) slab[tid] = 0.f;
@@ -947,12 +962,16 @@ struct WsLayout {
     int nblk;
 };
 
+constexpr int WL_MAX_B = 4095;      // samples per launch of the fused kernels (ticket capacity)
+
 inline WsLayout ws_layout(int B, int H, int W) {
     WsLayout l;
     l.nblk = ((W + TW - 1) / TW) * 2 * ((H + T2H - 1) / T2H);      // >= the workgroups per sample of every kernel that writes the slab
+    // The tickets sit at a FIXED place and size, whatever (B, H, W): a caller's cached workspace serves launches of different shapes, and a
+    // ticket word that another shape's slab had used would not be zero.  Nothing else is ever written to this region.
     size_t o = 0;
+    l.tick_off = o; o = align_up(o + sizeof(unsigned) * ((size_t)WL_MAX_B + 1), 256);
     l.pc_off = o;   o = align_up(o + sizeof(PrepConst) * (size_t)B, 256);
-    l.tick_off = o; o = align_up(o + sizeof(unsigned) * ((size_t)B + 1), 256);
     l.slab_off = o; o = align_up(o + sizeof(float) * SLAB * (size_t)B * l.nblk, 256);
     l.sl_off = o;   o = align_up(o + sizeof(double) * 2 * (size_t)B, 256);
     l.total = o;
@@ -960,15 +979,33 @@ inline WsLayout ws_layout(int B, int H, int W) {
 }
 
 // workgroups per sample of the fused L1 kernel: pass 0 (warps 0, 1 + smoothness: ~2.7 units of work per tile) and pass 1 (warp 2: 1 unit), sized
-// so that every workgroup of the launch is resident at once (256 CUs x 4) and the two kinds take about the same time
+// so that every workgroup of the launch is resident at once (CUs x workgroups per CU, asked of the runtime) and the two kinds take about the
+// same time -- a second, partly filled generation would double the launch's duration
+inline int l1_slots() {
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 256, per_cu = 3;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, warp_loss_l1_kernel<false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 3;
+        (void)hipGetLastError();
+        slots = cus * per_cu;
+    }
+    return slots;
+}
+
 inline void l1_grid(int B, int H, int W, int& G0, int& G1) {
     const int ntiles = ((W + TW - 1) / TW) * ((H + T2H - 1) / T2H);
-    const int per_sample = 1024 / B > 0 ? 1024 / B : 1;
+    const int slots = l1_slots();
+    const int per_sample = slots / B > 0 ? slots / B : 1;
     int n0 = (int)((ntiles * 1.37f + per_sample - 1) / per_sample);
     if (n0 < 1) n0 = 1;
-    const int n1 = (int)(2.7f * n0 + 0.999f);
-    G0 = (ntiles + n0 - 1) / n0;
-    G1 = (ntiles + n1 - 1) / n1;
+    for (;; ++n0) {
+        const int n1 = (int)(2.7f * n0 + 0.999f);
+        G0 = (ntiles + n0 - 1) / n0;
+        G1 = (ntiles + n1 - 1) / n1;
+        if ((G0 + G1) * B <= slots || G0 + G1 <= 2) break;       // (rounding up twice can overshoot by a few workgroups)
+    }
 }
 
 inline dim3 pix_grid(int B, int H, int W) { return dim3((W + TW - 1) / TW, (H + TH - 1) / TH, B); }
@@ -990,7 +1027,7 @@ static int warp_loss_launch(const float* tgt, const float* ref0, const float* re
                             void* workspace, size_t workspace_bytes, void* stream, float* dbg) {
     if (!tgt || !ref0 || !ref1 || !disp_t || !disp_r0 || !poses || !K || !losses || !d_disp_t || !d_disp_r0 || !d_poses || !workspace)
         return MCAV_E_INVALID;
-    if (B <= 0 || H < 3 || W < 3 || B > 65535) return MCAV_E_INVALID;
+    if (B <= 0 || H < 3 || W < 3 || B > WL_MAX_B) return MCAV_E_INVALID;
     const WsLayout l = ws_layout(B, H, W);
     if (workspace_bytes < l.total) return MCAV_E_WORKSPACE;
     char* ws = reinterpret_cast<char*>(workspace);
