@@ -117,6 +117,26 @@ size_t mcav_wgrad_workspace_bytes(const mcav_wgrad_desc* d);
 int mcav_wgrad_uses_bf16(const mcav_wgrad_desc* d);
 int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Batched slab reduction.  mcav_wgrad = GEMM (partial tiles of the pixel splits into a slab) + one or two reduction launches per layer: 68
+ * small launches per step for ResNet-18 + PoseNet.  mcav_wgrad_deferred runs the GEMM only and describes the pending reduction in *item (HOST
+ * memory; the workspace must stay untouched until it has been reduced: one workspace per pending layer).  The caller collects the items of a
+ * gradient bucket (autograd's backward of reference trainer.py:264 fills them in launch order), calls mcav_wgrad_reduce_plan once on the host
+ * array (fills the first-block columns; returns the two grids and the dynamic LDS size), copies the array to the device -- it does not change from
+ * step to step, so once -- and reduces all of them with mcav_wgrad_reduce_multi: one presum + one reduce launch, the per-layer kernels' bodies and
+ * summation order (bit-identical gradients). */
+typedef struct mcav_wgrad_reduce_item {
+    const float* slab;
+    float* pre;
+    float* dw;
+    float* dbias;
+    unsigned long long elems;
+    int splits, groups, per_group, Ktot, slabN, Kp, taps, Cout, Cin, ci_t, accumulate, upm, cin_total, ci_off;
+    int pre_bx, red_gx, red_gy, pre_first, red_first, reserved;
+} mcav_wgrad_reduce_item;
+int mcav_wgrad_deferred(const mcav_wgrad_desc* d, void* workspace, size_t workspace_bytes, mcav_wgrad_reduce_item* item, void* stream);
+int mcav_wgrad_reduce_plan(mcav_wgrad_reduce_item* items, int n, int* presum_blocks, int* reduce_blocks, size_t* lds_bytes);
+int mcav_wgrad_reduce_multi(const mcav_wgrad_reduce_item* items_dev, int n, int presum_blocks, int reduce_blocks, size_t lds_bytes, void* stream);
+
 /* OIHW [Cout][Cin][kh][kw] -> packed forward filter [Np][taps][Kp] (transposed = 0)
  *                          or packed data-gradient filter [Kp'][taps][Np'] with in/out swapped (transposed = 1). */
 int mcav_pack_weights(const float* w_oihw, int Cout, int Cin, int kh, int kw, int transposed, float* packed, int Np, int Kp,

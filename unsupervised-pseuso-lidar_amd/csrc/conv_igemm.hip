@@ -1456,11 +1456,11 @@ __global__ __launch_bounds__(256, (T::BM == 64 && T::BN == 64) ? 4 : ((T::BM == 
 }
 
 // First reduction level when there are many pixel splits: dst[g][e] = sum of the splits of group g (fixed order).
-__global__ __launch_bounds__(256) void wgrad_presum_kernel(const float* slab, int splits, size_t elems, int per_group, float* dst) {
+__device__ __forceinline__ void wgrad_presum_body(const float* slab, int splits, size_t elems, int per_group, float* dst, unsigned bx, unsigned by) {
     // elems is a multiple of 16 (slabN is): 16-byte accesses, four independent partial sums keep several loads in flight
-    const size_t e4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t e4 = (size_t)bx * 256 + threadIdx.x;
     if (e4 * 4 >= elems) return;
-    const int k0 = blockIdx.y * per_group, k1 = min(splits, k0 + per_group);
+    const int k0 = by * per_group, k1 = min(splits, k0 + per_group);
     const f32x4* src = reinterpret_cast<const f32x4*>(slab) + e4;
     const size_t stride4 = elems / 4;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
@@ -1472,7 +1472,11 @@ __global__ __launch_bounds__(256) void wgrad_presum_kernel(const float* slab, in
         s3 += src[(size_t)(k + 3) * stride4];
     }
     for (; k < k1; ++k) s0 += src[(size_t)k * stride4];
-    reinterpret_cast<f32x4*>(dst)[(size_t)blockIdx.y * stride4 + e4] = (s0 + s1) + (s2 + s3);
+    reinterpret_cast<f32x4*>(dst)[(size_t)by * stride4 + e4] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(256) void wgrad_presum_kernel(const float* slab, int splits, size_t elems, int per_group, float* dst) {
+    wgrad_presum_body(slab, splits, elems, per_group, dst, blockIdx.x, blockIdx.y);
 }
 
 // slab [splits][Ktot + 1][slabN] -> OIHW gradient (+ bias gradient), fixed summation order, optional accumulate.
@@ -1480,10 +1484,9 @@ __global__ __launch_bounds__(256) void wgrad_presum_kernel(const float* slab, in
 // the tile is transposed through LDS, and each output channel's run of CI_T * taps floats is written contiguously.
 // upm: the slab holds 16 x Kp rows (class, merged tap, ci); filter tap (ky, kx) = the sum over the four classes of the merged tap it belongs to.
 // Cin_total / ci_off: the OIHW tensor written has Cin_total input channels and this launch owns [ci_off, ci_off + Cin) of them.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, int splits, int Ktot, int slabN, int Kp, int taps, int Cout, int Cin,
-                                                           int CI_T, float* dw, float* dbias, int accumulate, int upm, int Cin_total, int ci_off) {
-    extern __shared__ float lds[];
-    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * CI_T;
+__device__ __forceinline__ void wgrad_reduce_body(float* lds, const float* slab, int splits, int Ktot, int slabN, int Kp, int taps, int Cout, int Cin,
+                                                  int CI_T, float* dw, float* dbias, int accumulate, int upm, int Cin_total, int ci_off, int bx, int by) {
+    const int co0 = bx * 32, ci0 = by * CI_T;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int run = CI_T * taps, stride = run + 1;
     const size_t split_stride = (size_t)(Ktot + 1) * slabN;
@@ -1539,7 +1542,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, in
                 if (at[u] >= 0) lds[at[u]] = sum[u];
         }
     }
-    if (dbias && blockIdx.y == 0 && ty == 0 && co0 + tx < Cout) {
+    if (dbias && by == 0 && ty == 0 && co0 + tx < Cout) {
         const float* src = slab + (size_t)Ktot * slabN + co0 + tx;
         float sum = 0.f;
         for (int k = 0; k < splits; ++k) sum += src[(size_t)k * split_stride];
@@ -1555,6 +1558,51 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, in
             dw[o] = accumulate ? dw[o] + v : v;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab, int splits, int Ktot, int slabN, int Kp, int taps, int Cout, int Cin,
+                                                           int CI_T, float* dw, float* dbias, int accumulate, int upm, int Cin_total, int ci_off) {
+    extern __shared__ float lds[];
+    wgrad_reduce_body(lds, slab, splits, Ktot, slabN, Kp, taps, Cout, Cin, CI_T, dw, dbias, accumulate, upm, Cin_total, ci_off, blockIdx.x, blockIdx.y);
+}
+
+// Batched form (mcav_wgrad_deferred + mcav_wgrad_reduce_multi): the weight-gradient GEMMs of a whole gradient bucket leave their slabs in
+// place and ONE presum launch + ONE reduce launch sum them all, a device table of items telling every workgroup which layer it belongs to.
+// Same bodies, same fixed summation order: bit-identical to the per-layer launches (68 launches per step -> 2 per bucket).
+__device__ __forceinline__ int find_item(const mcav_wgrad_reduce_item* items, int n, int blk, bool presum) {
+    int lo = 0;
+    for (int i = 1; i < n; ++i)
+        if ((presum ? items[i].pre_first : items[i].red_first) <= blk) lo = i;      // first-block columns are non-decreasing
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void wgrad_presum_multi_kernel(const mcav_wgrad_reduce_item* items, int n) {
+    __shared__ int s_i;
+    if (threadIdx.x == 0) {
+        int best = -1;
+        for (int i = 0; i < n; ++i)
+            if (items[i].groups > 0 && items[i].pre_first <= (int)blockIdx.x) best = i;
+        s_i = best;
+    }
+    __syncthreads();
+    if (s_i < 0) return;
+    const mcav_wgrad_reduce_item it = items[s_i];
+    const int local = (int)blockIdx.x - it.pre_first;
+    if (local >= it.pre_bx * it.groups) return;
+    wgrad_presum_body(it.slab, it.splits, (size_t)it.elems, it.per_group, it.pre, (unsigned)(local % it.pre_bx), (unsigned)(local / it.pre_bx));
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const mcav_wgrad_reduce_item* items, int n) {
+    extern __shared__ float lds[];
+    __shared__ int s_i;
+    if (threadIdx.x == 0) s_i = find_item(items, n, (int)blockIdx.x, false);
+    __syncthreads();
+    const mcav_wgrad_reduce_item it = items[s_i];
+    const int local = (int)blockIdx.x - it.red_first;
+    if (local >= it.red_gx * it.red_gy) return;
+    const float* src = it.groups > 0 ? it.pre : it.slab;
+    wgrad_reduce_body(lds, src, it.groups > 0 ? it.groups : it.splits, it.Ktot, it.slabN, it.Kp, it.taps, it.Cout, it.Cin, it.ci_t, it.dw, it.dbias,
+                      it.accumulate, it.upm, it.cin_total, it.ci_off, local % it.red_gx, local / it.red_gx);
 }
 
 // OIHW -> packed.  transposed = 0: packed[n = co][tap][k = ci];  transposed = 1: packed[n = ci][tap][k = co].
@@ -2047,12 +2095,13 @@ MCAV_EXPORT int mcav_wgrad_uses_bf16(const mcav_wgrad_desc* d) {
     return d && d->mma == 1 && mcav_bf16_wgrad_plan(d, pl);
 }
 
-MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
-    WgradPlan pl;
+// the GEMM part of a weight gradient: partial tiles into the slab at `workspace`
+static int wgrad_gemm(const mcav_wgrad_desc* d, void* workspace, size_t workspace_bytes, hipStream_t s, WgradPlan& pl) {
     const bool bf16 = d && d->mma == 1 && mcav_bf16_wgrad_plan(d, pl);      // bf16 MFMA tiles where the launch qualifies (conv_bf16.hip)
     if ((!bf16 && !plan_wgrad(d, pl)) || !workspace) return MCAV_E_INVALID;
     if (workspace_bytes < pl.slab_bytes + pl.pre_bytes) return MCAV_E_WORKSPACE;
-    hipStream_t s = as_stream(stream);
+    const int cin_total = d->Cin_total > 0 ? d->Cin_total : d->Cin;
+    if (d->ci_offset < 0 || d->ci_offset + d->Cin > cin_total) return MCAV_E_INVALID;
     pl.p.slab = reinterpret_cast<float*>(workspace);
     if (bf16) mcav_bf16_wgrad_launch(pl.p, s);
     else if (pl.use_stem) mcav_stem_wgrad_launch(d, pl.p.slab, pl.p.Ktot, pl.p.slabN, pl.p.splits, s);
@@ -2066,24 +2115,80 @@ MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t wor
         case 7: launch_wgrad<Tile128x32>(pl.p, pl.use_tab, s); break;
         default: return MCAV_E_INVALID;
     }
-    const dim3 rgrid((d->Cout + 31) / 32, (d->Cin + pl.ci_t - 1) / pl.ci_t);
-    const int out_taps = pl.p.upm ? 9 : pl.p.taps;
-    const size_t lds_bytes = sizeof(float) * 32 * (size_t)(pl.ci_t * out_taps + 1);
-    const float* rsrc = pl.p.slab;
-    int rsplits = pl.p.splits;
-    if (pl.groups) {
-        float* pre = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pl.slab_bytes);
-        const size_t elems = (size_t)(pl.p.Ktot + 1) * pl.p.slabN;
+    return MCAV_OK;
+}
+
+static void fill_reduce_item(const mcav_wgrad_desc* d, const WgradPlan& pl, void* workspace, mcav_wgrad_reduce_item& it) {
+    it.slab = pl.p.slab;
+    it.pre = pl.groups ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pl.slab_bytes) : nullptr;
+    it.dw = d->dw_oihw;
+    it.dbias = d->dbias;
+    it.elems = (unsigned long long)(pl.p.Ktot + 1) * pl.p.slabN;
+    it.splits = pl.p.splits; it.groups = pl.groups; it.per_group = pl.per_group;
+    it.Ktot = pl.p.Ktot; it.slabN = pl.p.slabN; it.Kp = pl.p.Kp;
+    it.taps = pl.p.upm ? 9 : pl.p.taps;
+    it.Cout = d->Cout; it.Cin = d->Cin; it.ci_t = pl.ci_t;
+    it.accumulate = d->accumulate; it.upm = pl.p.upm;
+    it.cin_total = d->Cin_total > 0 ? d->Cin_total : d->Cin;
+    it.ci_off = d->ci_offset;
+    it.pre_bx = pl.groups ? (int)((it.elems / 4 + 255) / 256) : 0;
+    it.red_gx = (d->Cout + 31) / 32;
+    it.red_gy = (d->Cin + pl.ci_t - 1) / pl.ci_t;
+    it.pre_first = 0; it.red_first = 0;
+}
+
+MCAV_EXPORT int mcav_wgrad(const mcav_wgrad_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    WgradPlan pl;
+    hipStream_t s = as_stream(stream);
+    const int rc = wgrad_gemm(d, workspace, workspace_bytes, s, pl);
+    if (rc != MCAV_OK) return rc;
+    mcav_wgrad_reduce_item it;
+    fill_reduce_item(d, pl, workspace, it);
+    const size_t lds_bytes = sizeof(float) * 32 * (size_t)(it.ci_t * it.taps + 1);
+    const float* rsrc = it.slab;
+    int rsplits = it.splits;
+    if (it.groups) {
         // (timed with the GEMM: the weight gradient is not finished until the slab is reduced -- bench.py's wgrad stage counts both)
-        timed_launch(wgrad_presum_kernel, dim3((unsigned)((elems / 4 + 255) / 256), pl.groups), dim3(256), 0, s, (const float*)pl.p.slab, pl.p.splits, elems,
-                     pl.per_group, pre);
-        rsrc = pre;
-        rsplits = pl.groups;
+        timed_launch(wgrad_presum_kernel, dim3((unsigned)it.pre_bx, it.groups), dim3(256), 0, s, (const float*)it.slab, it.splits, (size_t)it.elems,
+                     it.per_group, it.pre);
+        rsrc = it.pre;
+        rsplits = it.groups;
     }
-    const int cin_total = d->Cin_total > 0 ? d->Cin_total : d->Cin;
-    if (d->ci_offset < 0 || d->ci_offset + d->Cin > cin_total) return MCAV_E_INVALID;
-    timed_launch(wgrad_reduce_kernel, rgrid, dim3(256), lds_bytes, s, rsrc, rsplits, pl.p.Ktot, pl.p.slabN, pl.p.Kp, out_taps, d->Cout, d->Cin, pl.ci_t,
-                 d->dw_oihw, d->dbias, d->accumulate, pl.p.upm, cin_total, d->ci_offset);
+    timed_launch(wgrad_reduce_kernel, dim3(it.red_gx, it.red_gy), dim3(256), lds_bytes, s, rsrc, rsplits, it.Ktot, it.slabN, it.Kp, it.taps, it.Cout, it.Cin,
+                 it.ci_t, it.dw, it.dbias, it.accumulate, it.upm, it.cin_total, it.ci_off);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_wgrad_deferred(const mcav_wgrad_desc* d, void* workspace, size_t workspace_bytes, mcav_wgrad_reduce_item* item, void* stream) {
+    if (!item) return MCAV_E_INVALID;
+    WgradPlan pl;
+    const int rc = wgrad_gemm(d, workspace, workspace_bytes, as_stream(stream), pl);
+    if (rc != MCAV_OK) return rc;
+    fill_reduce_item(d, pl, workspace, *item);
+    return launch_status();
+}
+
+MCAV_EXPORT int mcav_wgrad_reduce_plan(mcav_wgrad_reduce_item* items, int n, int* presum_blocks, int* reduce_blocks, size_t* lds_bytes) {
+    if (!items || n <= 0 || !presum_blocks || !reduce_blocks || !lds_bytes) return MCAV_E_INVALID;
+    int pb = 0, rb = 0;
+    size_t lds = 0;
+    for (int i = 0; i < n; ++i) {
+        items[i].pre_first = pb;
+        items[i].red_first = rb;
+        pb += items[i].pre_bx * items[i].groups;
+        rb += items[i].red_gx * items[i].red_gy;
+        const size_t l = sizeof(float) * 32 * (size_t)(items[i].ci_t * items[i].taps + 1);
+        if (l > lds) lds = l;
+    }
+    *presum_blocks = pb; *reduce_blocks = rb; *lds_bytes = lds;
+    return MCAV_OK;
+}
+
+MCAV_EXPORT int mcav_wgrad_reduce_multi(const mcav_wgrad_reduce_item* items_dev, int n, int presum_blocks, int reduce_blocks, size_t lds_bytes, void* stream) {
+    if (!items_dev || n <= 0 || reduce_blocks <= 0 || presum_blocks < 0) return MCAV_E_INVALID;
+    hipStream_t s = as_stream(stream);
+    if (presum_blocks > 0) timed_launch(wgrad_presum_multi_kernel, dim3(presum_blocks), dim3(256), 0, s, items_dev, n);
+    timed_launch(wgrad_reduce_multi_kernel, dim3(reduce_blocks), dim3(256), lds_bytes, s, items_dev, n);
     return launch_status();
 }
 

@@ -35,7 +35,17 @@ class WgradDesc(ctypes.Structure):
                 ("mma", c_i)]
 
 
+class WgradReduceItem(ctypes.Structure):
+    """include/mcav_conv.h: mcav_wgrad_reduce_item (a pending slab reduction of one weight-gradient launch)."""
+    _fields_ = [("slab", c_p), ("pre", c_p), ("dw", c_p), ("dbias", c_p), ("elems", ctypes.c_ulonglong)] + \
+               [(n, c_i) for n in ("splits", "groups", "per_group", "Ktot", "slabN", "Kp", "taps", "Cout", "Cin", "ci_t", "accumulate", "upm", "cin_total",
+                                   "ci_off", "pre_bx", "red_gx", "red_gy", "pre_first", "red_first", "reserved")]
+
+
 L.register({
+    "mcav_wgrad_deferred": (c_i, [ctypes.POINTER(WgradDesc), c_p, c_sz, ctypes.POINTER(WgradReduceItem), c_p]),
+    "mcav_wgrad_reduce_plan": (c_i, [ctypes.POINTER(WgradReduceItem), c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_sz)]),
+    "mcav_wgrad_reduce_multi": (c_i, [c_p, c_i, c_i, c_i, c_sz, c_p]),
     "mcav_igemm_mtiles": (c_i, [ctypes.POINTER(IgemmDesc)]),
     "mcav_igemm": (c_i, [ctypes.POINTER(IgemmDesc), c_p]),
     "mcav_igemm_uses_bf16": (c_i, [ctypes.POINTER(IgemmDesc)]),
@@ -562,6 +572,7 @@ class _WgradSide:
 
     def join(self):
         cur = torch.cuda.current_stream()
+        flush_wgrad_batch()                  # the last gradient bucket's slabs: reduced behind their GEMMs, on the stream those ran on
         if self.forked:
             for m in self.mains:
                 m.wait_stream(self.stream)
@@ -584,8 +595,68 @@ GRADS_READY = None
 
 
 def grads_ready(params):
+    """A network's backward calls this when every gradient of a group of parameters has been issued (a bucket boundary): the pending slab
+    reductions of the bucket go out as one batch, then the data-parallel hook (if any) may all-reduce the bucket."""
+    flush_wgrad_batch()
     if GRADS_READY is not None:
         GRADS_READY(list(params))
+
+
+def flush_wgrad_batch():
+    """Issue the pending slab reductions on the stream their GEMMs were issued on (the weight-gradient side stream once it has forked)."""
+    if WGRAD_BATCH.items:
+        if WGRAD_SIDE.forked:
+            with torch.cuda.stream(WGRAD_SIDE.stream):
+                WGRAD_BATCH.flush()
+        else:
+            WGRAD_BATCH.flush()
+
+
+class _WgradBatch:
+    """Weight-gradient slab reductions of a gradient bucket as ONE presum + ONE reduce launch (mcav_wgrad_deferred / mcav_wgrad_reduce_multi).
+    Inside a backward pass every weight-gradient GEMM leaves its slab in its own buffer (the k-th pending launch uses pool[k]: the launch
+    sequence of a step is static, so the buffers and therefore the device tables are the same every step -- a table is built once per
+    launch sequence).  Outside a backward pass (direct calls, the instrumented steps of bench.py) the per-layer launches run."""
+
+    def __init__(self):
+        self.enabled = os.environ.get("MCAV_WGRAD_BATCH", "1") != "0"
+        self.items = []           # WgradReduceItem of the pending launches
+        self.targets = set()      # (gradient pointer, first input channel) of the pending launches
+        self.pool = {}            # (device, k) -> byte buffer of the k-th pending launch
+        self.tables = {}          # bytes of the planned item array -> (device table, presum blocks, reduce blocks, lds bytes)
+        self.device = None
+
+    def buffer(self, nbytes, device):
+        k = (str(device), len(self.items))
+        buf = self.pool.get(k)
+        if buf is None or buf.numel() < nbytes:
+            buf = self.pool[k] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self.tables.clear()                  # (pointers moved)
+        self.device = device
+        return buf
+
+    def flush(self):
+        n = len(self.items)
+        if n == 0:
+            return
+        arr = (WgradReduceItem * n)(*self.items)
+        self.items = []
+        self.targets = set()
+        pb, rb, lds = c_i(0), c_i(0), c_sz(0)
+        h = L.lib()
+        L.check(h.mcav_wgrad_reduce_plan(arr, n, ctypes.byref(pb), ctypes.byref(rb), ctypes.byref(lds)), "mcav_wgrad_reduce_plan")
+        key = (str(self.device), bytes(arr))
+        hit = self.tables.get(key)
+        if hit is None:
+            table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            hit = self.tables[key] = (table, pb.value, rb.value, lds.value)
+        table, npb, nrb, nlds = hit
+        with _Timed("wgrad", 0.0, "slab reduction of %d weight gradients (batched)" % n):
+            L.check(h.mcav_wgrad_reduce_multi(P(table), n, npb, nrb, nlds, L.stream()), "mcav_wgrad_reduce_multi")
+
+
+import os
+WGRAD_BATCH = _WgradBatch()
 
 
 def launch_wgrad(d, tensors, flops=0.0, tag="", executed=None):
@@ -595,8 +666,28 @@ def launch_wgrad(d, tensors, flops=0.0, tag="", executed=None):
     if nbytes == 0:
         raise L.MCAVError("mcav_wgrad: invalid descriptor")
 
+    dev = tensors[0].device
+    defer = WGRAD_BATCH.enabled and PROFILE is None and dev.type == "cuda" and WGRAD_SIDE._note(torch.cuda.current_stream())
+    if defer:
+        # inside a backward pass: GEMM now, the slab reduction with its bucket (grads_ready / the end-of-backward join).  The descriptor is
+        # copied: the caller re-uses `d` for its next launch.
+        target = (d.dw_oihw, d.ci_offset)
+        if target in WGRAD_BATCH.targets:        # a second launch into the same gradient (separate depth passes): its accumulate must see the first
+            flush_wgrad_batch()
+        WGRAD_BATCH.targets.add(target)
+        ws = WGRAD_BATCH.buffer(nbytes, dev)
+        item = WgradReduceItem()
+        dd = WgradDesc.from_buffer_copy(d)
+
+        def go_deferred():
+            with _Timed("wgrad", flops, tag, executed):
+                L.check(h.mcav_wgrad_deferred(ctypes.byref(dd), P(ws), ws.numel(), ctypes.byref(item), L.stream()), "mcav_wgrad_deferred")
+        WGRAD_SIDE.run(go_deferred, tensors)
+        WGRAD_BATCH.items.append(item)
+        return
+
     def go():
-        ws = L.workspace(nbytes, tensors[0].device, "wgrad")
+        ws = L.workspace(nbytes, dev, "wgrad")
         with _Timed("wgrad", flops, tag, executed):
             L.check(h.mcav_wgrad(ctypes.byref(d), P(ws), ws.numel(), L.stream()), "mcav_wgrad")
     WGRAD_SIDE.run(go, tensors)
