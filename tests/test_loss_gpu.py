@@ -298,8 +298,11 @@ def test_multiscale_losses_vs_oracle(ssim):
     assert abs(float(got[1]) - float(want[1])) < 2e-5 * abs(float(want[1]))
     sum(got).backward()
     for i in range(4):
-        grad_close(x[i].grad, a[i].grad, frac=5e-3, l2=5e-3)
-        grad_close(y[i].grad, b[i].grad, frac=5e-3, l2=5e-3)
+        # a tie pixel (L1 sign / bilinear cell, tests/flip_finder.py) of a full-resolution warp reaches FOUR elements of a coarse map through
+        # the bilinear resize: two such pixels are 3 % of the coarsest 2 x 8 x 16 gradient, so the allowed fraction has a floor in elements
+        frac = max(5e-3, 8.0 / x[i].grad.numel())
+        grad_close(x[i].grad, a[i].grad, frac=frac, l2=5e-3)
+        grad_close(y[i].grad, b[i].grad, frac=frac, l2=5e-3)
     assert rel_err(z.grad, c.grad) < 5e-3
 
 

@@ -92,7 +92,7 @@ __global__ void pose_prepare_kernel(const float* poses, const void* K, const flo
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 // Reduce N per-thread floats over a 256-thread block and store them at dst[0..N).
-template <int N>
+template <int N, bool AGENT = false>
 __device__ __forceinline__ void block_reduce_store(float* acc, float* dst, float (*sred)[SLAB]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -102,7 +102,11 @@ __device__ __forceinline__ void block_reduce_store(float* acc, float* dst, float
         for (int k = 0; k < N; ++k) sred[wave][k] = acc[k];
     }
     __syncthreads();
-    if (threadIdx.x < N) dst[threadIdx.x] = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+    if (threadIdx.x < N) {
+        const float v = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+        if constexpr (AGENT) __hip_atomic_store(dst + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else dst[threadIdx.x] = v;
+    }
 }
 
 // Branch-free bilinear gathers: an image (3 planes) is a raw buffer resource, a tap outside the image carries an out-of-range offset and
@@ -206,6 +210,13 @@ __device__ __forceinline__ WarpFast uniform_warp(const WarpFast& w) {
     return u;
 }
 
+// What one workgroup writes for ANOTHER to read inside the same launch (slab entries, per-sample sums) is stored and loaded at agent
+// scope (sc1: through to / from the coherence point, past the XCD-local L2), ordered by s_waitcnt in front of the ticket.  The first
+// version used __threadfence(), i.e. a write-back and invalidate of the XCD's whole L2 per workgroup: 660 (L1) / 3840 (SSIM) of those per
+// launch took the gathers' cached lines with them and doubled the kernels' time.
+__device__ __forceinline__ void slab_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void order_before_ticket() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+
 constexpr int RED_LD = 256 + 8;      // one pad float per 32 threads: the transposed reads are conflict-free
 
 // Sum N per-thread values over the 256 threads (fixed order) into out[slot(k)]: each value's 256 addends are written to LDS, 8 lanes
@@ -225,18 +236,17 @@ __device__ __forceinline__ void block_sum_to_slab(const float* acc, float (*sred
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 4, 64);
-    if (k < N && part == 0) out[slot(k)] = s;
+    if (k < N && part == 0) slab_store(out + slot(k), s);
 }
 
 // after the workgroup's slab entry is written: ticket, and the last workgroup of the sample finishes the sample
 __device__ __forceinline__ void block_finish(const WLArgs& a, int b, int nblk, double (*s64)[SLAB], int* s_flag) {
     const int tid = threadIdx.x;
-    __threadfence();                                             // this workgroup's slab entry is visible device-wide ...
+    order_before_ticket();                                       // this workgroup's (agent-scope) slab stores have completed ...
     __syncthreads();
-    if (tid == 0) *s_flag = atomicAdd(&a.tickets[b], 1u) == (unsigned)(nblk - 1);      // ... before its ticket is
+    if (tid == 0) *s_flag = __hip_atomic_fetch_add(&a.tickets[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblk - 1);      // ... before its ticket is taken
     __syncthreads();
     if (!*s_flag) return;
-    __threadfence();
     const float* slab = a.slab + (size_t)b * nblk * SLAB;
     constexpr int PARTS = 256 / SLAB;                            // 6 x 40 = 240 threads
     if (tid < PARTS * SLAB) {
@@ -269,12 +279,11 @@ __device__ __forceinline__ void block_finish(const WLArgs& a, int b, int nblk, d
             a.d_poses[(size_t)b * 12 + i] = (float)(s64[1][i] + s64[3][i]);      // pose[0]: warp 0 and (through its inverse) warp 2
             a.d_poses[(size_t)b * 12 + 6 + i] = (float)s64[2][i];
         }
-        a.sample_loss[b * 2 + 0] = s64[0][0];
-        a.sample_loss[b * 2 + 1] = s64[0][1];
-        a.tickets[b] = 0;
-        __threadfence();
-        if (atomicAdd(&a.tickets[a.B], 1u) == (unsigned)(a.B - 1)) {
-            __threadfence();
+        __hip_atomic_store(a.sample_loss + b * 2 + 0, s64[0][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.sample_loss + b * 2 + 1, s64[0][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.tickets[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        order_before_ticket();
+        if (__hip_atomic_fetch_add(&a.tickets[a.B], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.B - 1)) {
             double l0 = 0.0, l1 = 0.0;
             for (int i = 0; i < a.B; ++i) {
                 l0 += __hip_atomic_load(a.sample_loss + i * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -282,7 +291,7 @@ __device__ __forceinline__ void block_finish(const WLArgs& a, int b, int nblk, d
             }
             a.losses[0] = (float)l0;
             a.losses[1] = (float)l1;
-            a.tickets[a.B] = 0;
+            __hip_atomic_store(&a.tickets[a.B], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(256, 3) void warp_loss_l1_kernel(WLArgs a) {
         }
         __syncthreads();                                         // (sD and sred do not alias, but every wavefront must be out of the loop's barriers)
         block_sum_to_slab<RED_N0>(acc, sred, slab, [](int k) { return k; });
-        if (tid >= RED_N0 && tid < SLAB) slab[tid] = 0.f;        // warp 2's slots
+        if (tid >= RED_N0 && tid < SLAB) slab_store(slab + tid, 0.f);      // warp 2's slots
     } else {
         // ---- pass 1: warp 2 (tgt sampled with depth(ref0) and the inverted pose[0], compared with ref1: losses.py:203-207); d loss / d disp(ref0)
         const float gw2 = g0 * a.tw[2] * invN, lw2 = a.tw[2] * invN;
@@ -508,8 +517,8 @@ __global__ __launch_bounds__(256, 3) void warp_loss_l1_kernel(WLArgs a) {
         }
         __syncthreads();                                         // (the stage and sred alias)
         block_sum_to_slab<RED_N1>(acc, sred, slab, [](int k) { return k == 0 ? 0 : 25 + k; });      // loss share; dP of warp 2 -> slots 26..37
-        if (tid >= 1 && tid < 26) slab[tid] = 0.f;
-        if (tid >= 38 && tid < SLAB) slab[tid] = 0.f;
+        if (tid >= 1 && tid < 26) slab_store(slab + tid, 0.f);
+        if (tid >= 38 && tid < SLAB) slab_store(slab + tid, 0.f);
     }
     block_finish(a, b, a.G0 + a.G1, reinterpret_cast<double (*)[SLAB]>(&sred[0][0]), &s_flag);
 }
@@ -765,8 +774,8 @@ __global__ __launch_bounds__(256) void warp_loss_ssim_kernel(WLArgs a) {
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
     float* const slab = a.slab + ((size_t)b * nblk + blk) * SLAB;
     __syncthreads();                                   // every reader of the constants (and of sC) is done: their LDS is re-used below
-    block_reduce_store<NACC>(acc, slab, sred);
-    if (threadIdx.x >= NACC && threadIdx.x < SLAB) slab[threadIdx.x] = 0.f;
+    block_reduce_store<NACC, true>(acc, slab, sred);
+    if (threadIdx.x >= NACC && threadIdx.x < SLAB) slab_store(slab + threadIdx.x, 0.f);
     block_finish(a, b, nblk, s64, &s_flag);
 }
 
