@@ -301,8 +301,9 @@ def test_multiscale_losses_vs_oracle(ssim):
         # a tie pixel (L1 sign / bilinear cell, tests/flip_finder.py) of a full-resolution warp reaches FOUR elements of a coarse map through
         # the bilinear resize: two such pixels are 3 % of the coarsest 2 x 8 x 16 gradient, so the allowed fraction has a floor in elements
         frac = max(5e-3, 8.0 / x[i].grad.numel())
-        grad_close(x[i].grad, a[i].grad, frac=frac, l2=5e-3)
-        grad_close(y[i].grad, b[i].grad, frac=frac, l2=5e-3)
+        l2 = 5e-3 if x[i].grad.numel() >= 4096 else 2e-2
+        grad_close(x[i].grad, a[i].grad, frac=frac, l2=l2)
+        grad_close(y[i].grad, b[i].grad, frac=frac, l2=l2)
     assert rel_err(z.grad, c.grad) < 5e-3
 
 
