@@ -7,6 +7,8 @@
 // reads), the tgt-depth tile (+2 halo) staged in LDS for the smoothness stencil, bilinear taps served from
 // L1/L2 (neighbouring pixels sample neighbouring source texels), deterministic two-level reduction
 // (wavefront shuffles -> LDS -> per-block slab -> fp64 finalize) for the 2 loss scalars and the 3x12 dP sums.
+#include <stdlib.h>
+
 #include "mcav_common.h"
 #include "kernel_timer.h"
 #include "warp_math.h"
@@ -1033,11 +1035,17 @@ inline int l1_slots() {
 inline void l1_grid(int B, int H, int W, int& G0, int& G1) {
     const int ntiles = ((W + TW - 1) / TW) * ((H + T2H - 1) / T2H);
     const int slots = l1_slots();
+    // cost of a pass-1 tile relative to a pass-0 tile.  Counted in instructions a pass-0 tile is 2.7 pass-1 tiles; measured (PMC pass of
+    // tools/pmc_loss.sh: wavefront residency per kind of workgroup) they take the SAME time -- a tile's duration is set by the chain of gather
+    // round trips per thread, which is as long in both -- so the tiles are dealt 1 : 1 (with 2.7 : 1 the pass-1 workgroups ran twice as long as
+    // the others and the launch took 121 us instead of 64).  MCAV_WL_RATIO overrides (experiments).
+    static const float ratio = [] { const char* e = getenv("MCAV_WL_RATIO"); const float r = e ? (float)atof(e) : 1.0f; return r > 0.05f ? r : 1.0f; }();
     const int per_sample = slots / B > 0 ? slots / B : 1;
-    int n0 = (int)((ntiles * 1.37f + per_sample - 1) / per_sample);
+    int n0 = (int)((ntiles * (1.0f + 1.0f / ratio) + per_sample - 1) / per_sample);
     if (n0 < 1) n0 = 1;
     for (;; ++n0) {
-        const int n1 = (int)(2.7f * n0 + 0.999f);
+        int n1 = (int)(ratio * n0 + 0.5f);
+        if (n1 < 1) n1 = 1;
         G0 = (ntiles + n0 - 1) / n0;
         G1 = (ntiles + n1 - 1) / n1;
         if ((G0 + G1) * B <= slots || G0 + G1 <= 2) break;       // (rounding up twice can overshoot by a few workgroups)
