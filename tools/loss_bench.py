@@ -26,6 +26,8 @@ g = torch.Generator().manual_seed(4)
 dt, dr = torch.rand(B, 1, H, W, generator=g).to(dev), torch.rand(B, 1, H, W, generator=g).to(dev)
 poses = (0.01 * torch.randn(B, 2, 6, generator=g)).to(dev)
 crit = Losses(ssim=a.ssim)
+from mcav import nn as N  # noqa: E402
+
 with torch.no_grad():
     for _ in range(20):
         out = crit.forward(tgt, refs, [[dt], [dr]], poses, K, None)
@@ -36,6 +38,14 @@ with torch.no_grad():
         out = crit.forward(tgt, refs, [[dt], [dr]], poses, K, None)
     e1.record()
     torch.cuda.synchronize()
-us = 1000.0 * e0.elapsed_time(e1) / a.iters
-print("loss stage %s %dx%dx%d: %.1f us per call (back-to-back launches, host included), %.3f of the 8 TB/s HBM roofline at 52 B/pixel; losses %s"
-      % ("SSIM+L1" if a.ssim else "L1", B, H, W, us, 52.0 * B * H * W / (us * 1e-6) / 8e12, [round(float(x), 6) for x in out]))
+    call_us = 1000.0 * e0.elapsed_time(e1) / a.iters
+    # the kernel's own duration: per-dispatch HIP events (csrc/kernel_timer.h), as bench.py's roofline_warp
+    N.kernel_timer_begin()
+    for _ in range(50):
+        out = crit.forward(tgt, refs, [[dt], [dr]], poses, K, None)
+    torch.cuda.synchronize()
+    durs = sorted(N.kernel_timer_end())
+us = 1000.0 * durs[len(durs) // 2]
+print("loss stage %s %dx%dx%d: kernel %.1f us (median of %d dispatches, min %.1f) = %.3f of the 8 TB/s HBM roofline at 52 B/pixel; %.1f us per "
+      "back-to-back call incl. the host; losses %s" % ("SSIM+L1" if a.ssim else "L1", B, H, W, us, len(durs), 1000.0 * durs[0],
+                                                       52.0 * B * H * W / (us * 1e-6) / 8e12, call_us, [round(float(x), 6) for x in out]))
