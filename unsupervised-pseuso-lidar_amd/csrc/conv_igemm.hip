@@ -365,8 +365,12 @@ __device__ unsigned long long g_diag_stamps[8];
 #define MCAV_STAMP_BEGIN()
 #define MCAV_STAMP(i)
 #endif
+#ifndef MCAV_IG_OCC
+#define MCAV_IG_OCC 1      // workgroups per SIMD asked of the register allocator for the 64x64 (32-deep) forward / adjoint kernel (`make variant`)
+#endif
 template <class T, int TK>
-__global__ __launch_bounds__(256, (T::BM == 128 && T::BN == 64 && T::KD == 16 && TK != 1) ? 4 : 1) void igemm_tab_kernel(IgemmParams p) {
+__global__ __launch_bounds__(256, (T::BM == 128 && T::BN == 64 && T::KD == 16 && TK != 1) ? 4
+                                  : ((T::BM == 64 && T::BN == 64 && T::KD == 32 && TK == 0) ? MCAV_IG_OCC : 1)) void igemm_tab_kernel(IgemmParams p) {
     constexpr bool REFL = TK == 1, UPM = TK == 2;
     constexpr int BM = T::BM, BN = T::BN, CKT = T::KD;
     __shared__ __attribute__((aligned(16))) float As[2][BM][T::LD];

@@ -1035,11 +1035,11 @@ inline int l1_slots() {
 inline void l1_grid(int B, int H, int W, int& G0, int& G1) {
     const int ntiles = ((W + TW - 1) / TW) * ((H + T2H - 1) / T2H);
     const int slots = l1_slots();
-    // cost of a pass-1 tile relative to a pass-0 tile.  Counted in instructions a pass-0 tile is 2.7 pass-1 tiles; measured (PMC pass of
-    // tools/pmc_loss.sh: wavefront residency per kind of workgroup) they take the SAME time -- a tile's duration is set by the chain of gather
-    // round trips per thread, which is as long in both -- so the tiles are dealt 1 : 1 (with 2.7 : 1 the pass-1 workgroups ran twice as long as
-    // the others and the launch took 121 us instead of 64).  MCAV_WL_RATIO overrides (experiments).
-    static const float ratio = [] { const char* e = getenv("MCAV_WL_RATIO"); const float r = e ? (float)atof(e) : 1.0f; return r > 0.05f ? r : 1.0f; }();
+    // tiles of a pass-1 workgroup per tile of a pass-0 workgroup.  Counted in instructions a pass-0 tile is 2.7 pass-1 tiles; measured on
+    // MI355X (tools/loss_bench.py, network-like disparities, 12 x 192x640 / 12 x 320x1024): 1.0 -> 73.8 / 201 us, 2.0 -> 66.2 / 171, 2.7 -> 69.2 /
+    // 172.  MCAV_WL_RATIO overrides (experiments).  Also measured and not kept: the smoothness tile's depths fetched a pixel ahead (68.4 us),
+    // a three-stage pipeline with 24 .. 48 gathers in flight at two wavefronts per SIMD (68.6 .. 73 us).
+    static const float ratio = [] { const char* e = getenv("MCAV_WL_RATIO"); const float r = e ? (float)atof(e) : 2.0f; return r > 0.05f ? r : 2.0f; }();
     const int per_sample = slots / B > 0 ? slots / B : 1;
     int n0 = (int)((ntiles * (1.0f + 1.0f / ratio) + per_sample - 1) / per_sample);
     if (n0 < 1) n0 = 1;
