@@ -27,7 +27,12 @@ class GraphedStep:
         keep = [arena.flat.clone(), opt._m.clone(), opt._v.clone()] + [b.clone() for b in buffers]
         step0 = opt._step
         hook, N.GRADS_READY = N.GRADS_READY, None          # no collectives from inside warm-up / capture (see the module docstring)
-        serial0, streams.SERIAL = streams.SERIAL, True     # this ROCm replays a captured graph on one queue: capture it on one stream
+        # Rounds 1-2 measured that this ROCm replays the captured branches on one queue, so the step is captured on ONE stream (same launches,
+        # no cross-stream edges).  MCAV_GRAPH_STREAMS=1 keeps the three streams in the capture (the runtime then needs its parallel graph
+        # queues, e.g. DEBUG_HIP_FORCE_GRAPH_QUEUES=4) -- an experiment knob; measurements in DESIGN.md section 5.
+        import os
+        multi = os.environ.get("MCAV_GRAPH_STREAMS", "0") == "1"
+        serial0, streams.SERIAL = streams.SERIAL, (streams.SERIAL if multi else True)
         try:
             def whole():
                 out = fwd_bwd(*self.static_in)
