@@ -27,12 +27,10 @@ class GraphedStep:
         keep = [arena.flat.clone(), opt._m.clone(), opt._v.clone()] + [b.clone() for b in buffers]
         step0 = opt._step
         hook, N.GRADS_READY = N.GRADS_READY, None          # no collectives from inside warm-up / capture (see the module docstring)
-        # Rounds 1-2 measured that this ROCm replays the captured branches on one queue, so the step is captured on ONE stream (same launches,
-        # no cross-stream edges).  MCAV_GRAPH_STREAMS=1 keeps the three streams in the capture (the runtime then needs its parallel graph
-        # queues, e.g. DEBUG_HIP_FORCE_GRAPH_QUEUES=4) -- an experiment knob; measurements in DESIGN.md section 5.
-        import os
-        multi = os.environ.get("MCAV_GRAPH_STREAMS", "0") == "1"
-        serial0, streams.SERIAL = streams.SERIAL, (streams.SERIAL if multi else True)
+        # This ROCm replays the captured branches on one queue (rounds 1-2), so the step is captured on ONE stream: same launches, no
+        # cross-stream edges.  (Round 3 tried to keep the three streams in the capture and force the runtime's parallel graph queues,
+        # DEBUG_HIP_FORCE_GRAPH_QUEUES=4: the process died inside the capture without a Python error; not pursued.)
+        serial0, streams.SERIAL = streams.SERIAL, True
         try:
             def whole():
                 out = fwd_bwd(*self.static_in)
