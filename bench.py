@@ -317,6 +317,8 @@ def main():
         torch.cuda.synchronize()
         durs = N.kernel_timer_end()
         recs = [(kind, fl, sum(durs[i0:i1])) for (kind, fl, i0, i1, _) in N.PROFILE]
+        # the slab reduction of a weight gradient = every dispatch of its record after the first (the GEMM); round 2's figure left it out
+        slab_ms = sum(sum(durs[i0 + 1:i1]) for (kind, _, i0, i1, _) in N.PROFILE if kind == "wgrad") / 3.0
         executed_flops = sum(ex for (_, _, _, _, ex) in N.PROFILE) / 3.0
         N.PROFILE = None
         streams.SERIAL = serial_before
@@ -353,6 +355,8 @@ def main():
                                            "in profiles/r02_traffic.json (null when absent)",
                            "kernel": "conv stage = implicit-GEMM forward / adjoint, weight-gradient (GEMM + its slab reduction: presum + reduce), halo and "
                                      "stencil kernels, all launches of one step; durations from per-dispatch HIP start/stop events",
+                           "frac_excluding_slab_reduction": round(flops / ((ms - slab_ms) * 1e-3) / 1e12 / peak, 4),
+                           "slab_reduction_ms_per_step": round(slab_ms, 3),
                            "launches_per_step": len(recs) // 3, "algorithmic_gflop_per_step": round(flops / 1e9, 2),
                            "kernel_ms_per_step": round(ms, 3),
                            "by_kind": {k: {"gflop": round(v[0] / 1e9, 2), "ms": round(v[1], 3), "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2),
