@@ -68,7 +68,7 @@ def measured_traffic(steps_in_profile=3):
     # 4 B per lane, an access width the guide leaves uncalibrated: undoubled, FETCH_SIZE equals the compulsory read bytes (11 planes) within
     # 1 %, so it is NOT doubled here (doubling would claim that every input plane is fetched twice).
     warp = [(v.get("fetch_size_kb_max_launch_raw", 0.0) + v.get("write_size_kb_max_launch_raw", 0.0)) * 1024.0
-            for n, v in k.items() if "warp_loss_kernel" in n]
+            for n, v in k.items() if "warp_loss_l1_kernel" in n or "warp_loss_kernel" in n]
     return conv / steps_in_profile, (warp[0] if warp and warp[0] > 0 else None)
 
 
