@@ -38,6 +38,8 @@ extern "C" {
 
 /* One gather-GEMM launch: y[pix, n] = epilogue( sum_{tap, c} src(pix, tap)[c] * w[n][tap][c] ).
  * Used for the forward convolution and (with the adjoint gather modes / transposed packed weights) for dgrad. */
+#define MCAV_DACT_AFTER_ADDEND 0x100
+
 typedef struct mcav_igemm_desc {
     /* source: logical [B, Hs, Ws, C1 + C2]; channels [0, C1) come from x1, [C1, C1+C2) from x2 (fused concat) */
     const float* x1;
@@ -56,7 +58,8 @@ typedef struct mcav_igemm_desc {
     const float* bias;
     int act;
     const float* dact_aux;  /* same layout as y; dact = MCAV_ACT_* whose derivative (as a function of the OUTPUT) multiplies */
-    int dact;
+    int dact;               /* | MCAV_DACT_AFTER_ADDEND: the factor multiplies AFTER the addend has been added ((conv + addend) * act'(aux): the gradient
+                             * arriving at a residual block's output ReLU is the sum of two branches) */
     const float* addend;    /* same layout as y */
     int pool;               /* 1: destination pixels are visited in 2x2 blocks and summed: y is [B, Hd/2, Wd/2, Cd] */
     float* stats;           /* NULL or [mtiles][2][n_count]: per-tile column sums of y and y^2 (BatchNorm batch statistics) */
@@ -75,6 +78,14 @@ typedef struct mcav_igemm_desc {
                              * merged-tap forms) run the fp32 kernels with w; mcav_igemm_uses_bf16() tells which. */
     const void* w16;        /* mma = 1: bf16 copy of the packed filter, same [Np][kh*kw][Kp] layout and row stride in ELEMENTS
                              * (mcav_pack_weights_multi with transposed | 2, or mcav_f32_to_bf16 of a packed fp32 copy) */
+    /* BatchNorm BACKWARD statistics in the epilogue of the data gradient that produces dy (round 3; with `stats`): when stats_x is set the
+     * second statistic of a column is the sum of y * xhat, xhat = (stats_x - stats_mean[g][n]) * stats_invstd[g][n], instead of the sum of
+     * y^2 -- y being what the epilogue stores (after the act'(dact_aux) factor and the addend), stats_x the raw output of the convolution
+     * whose BatchNorm is being differentiated (same layout as y), g the tile's group.  The slab then holds exactly the partial sums
+     * mcav_bn_bwd_reduce would have produced in a pass of its own over dy, the activations and x; mcav_bn_bwd_finalize sums it. */
+    const float* stats_x;
+    const float* stats_mean;
+    const float* stats_invstd;
     const float* w_stem;    /* NULL, or mcav_pack_stem_weights' copy of the filter: the 7x7 stride-2 stems (the image stem: SMALLC gather, 3 -> 64;
                              * PoseNet conv1: 9 of 16 stored channels -> 16) then run on the patch-in-LDS kernels of conv_stem.hip; ignored by
                              * every other launch */
@@ -228,6 +239,9 @@ int mcav_bn_bwd_reduce(const float* dy, const float* y_act, const float* x, cons
                        int groups, void* workspace, size_t workspace_bytes, void* stream);
 /* backward, pass 2: dx = gamma * invstd * (dz - sum_dz / N - xhat * sum_dz_xhat / N); optionally also stores dz (the
  * gradient flowing to the residual branch) to dres (added into it if dres_accumulate) */
+/* Second half of mcav_bn_bwd_reduce on its own: partial sums [groups][nblk][2][C] (the reduce kernel's, or the statistics slab of a data
+ * gradient launched with stats_x) -> sums [groups][2][C] and the (accumulated) gamma / beta gradients, fixed summation order in float64. */
+int mcav_bn_bwd_finalize(const float* partial, int nblk, int C, float* dgamma, float* dbeta, int accumulate, float* sums, int groups, void* stream);
 int mcav_bn_bwd_apply(const float* dy, const float* y_act, const float* x, const float* gamma, const float* save_mean,
                       const float* save_invstd, const float* sums, int relu, size_t n_pix, int C, float* dx, float* dres,
                       int dres_accumulate, int groups, void* stream);

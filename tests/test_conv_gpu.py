@@ -120,6 +120,56 @@ def test_conv_stats_and_epilogues():
     assert rel_err(nchw(got), want_dx) < 2e-5
 
 
+@pytest.mark.parametrize("B,H,W,C,k,groups,addend,tile", [(4, 12, 20, 64, 3, 2, True, 0), (2, 9, 14, 64, 3, 1, False, 2), (4, 6, 10, 128, 1, 2, True, 0),
+                                                          (6, 24, 40, 64, 3, 2, True, 1)])
+def test_dgrad_epilogue_carries_batchnorm_backward_sums(B, H, W, C, k, groups, addend, tile):
+    """Round 3: the data gradient that produces a BatchNorm's incoming gradient applies the ReLU mask -- after the residual addend where there
+    is one -- and leaves the BatchNorm-backward partial sums (sum g, sum g * xhat per tile and channel, per group) in a slab
+    (mcav_igemm_desc.stats_x); `mcav_bn_bwd_finalize` + `mcav_bn_bwd_apply` then give the same dx, dgamma, dbeta as the three-pass form."""
+    from mcav import nn as N
+    g = torch.Generator().manual_seed(7 * B + H)
+    cout = C
+    w = torch.randn(cout, C, k, k, generator=g) * (2.0 / (C * k * k)) ** 0.5
+    spec = N.ConvSpec(torch.nn.Parameter(w.to(DEV)), None, 1, k // 2, N.PAD_ZERO)
+    dy = torch.randn(B, cout, H, W, generator=g)
+    x_raw = torch.randn(B, C, H, W, generator=g)                 # the raw conv output of the BatchNorm being differentiated
+    y_act = F.relu(torch.randn(B, C, H, W, generator=g))         # its activated output (mask)
+    add = torch.randn(B, C, H, W, generator=g) if addend else None
+    st = N.BNState()
+    st.groups = groups
+    mean = 0.1 * torch.randn(groups, C, generator=g)
+    invstd = 0.5 + torch.rand(groups, C, generator=g)
+    st.mean, st.invstd = mean.to(DEV), invstd.to(DEV)
+    st.scale = st.shift = None
+    got, slab, mtg = N.conv_dgrad(spec, nhwc(dy), (H, W), dact_aux=nhwc(y_act), dact=N.ACT_RELU | (N.DACT_AFTER_ADDEND if addend else 0),
+                                  addend=None if add is None else nhwc(add), bn_stats=(nhwc(x_raw), st), tile=tile)
+    want = F.conv_transpose2d(dy.double(), w.double(), stride=1, padding=k // 2)
+    if add is not None:
+        want = want + add.double()
+    want = want * (y_act > 0).double()
+    assert rel_err(nchw(got), want) < 2e-5
+    # the slab's sums per group = the reduce pass's: sum of g and of g * xhat
+    per = B // groups
+    sums = slab.view(groups, mtg, 2, C).double().sum(1).cpu()
+    for gi in range(groups):
+        gsl = want[gi * per:(gi + 1) * per]
+        xh = (x_raw[gi * per:(gi + 1) * per].double() - mean[gi].double().view(1, C, 1, 1)) * invstd[gi].double().view(1, C, 1, 1)
+        assert rel_err(sums[gi, 0], gsl.sum((0, 2, 3))) < 1e-4
+        assert rel_err(sums[gi, 1], (gsl * xh).sum((0, 2, 3))) < 1e-4
+    # ... and the finalize + apply that follow equal the three-pass BatchNorm backward on the same (masked) gradient
+    bn = torch.nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.1 * torch.randn(C, generator=g))
+    bn.weight.grad = torch.zeros_like(bn.weight)
+    bn.bias.grad = torch.zeros_like(bn.bias)
+    dx_f = N.bn_backward(bn, st, got, None, nhwc(x_raw), True, fused=(slab, mtg))
+    gw_f, gb_f = bn.weight.grad.clone(), bn.bias.grad.clone()
+    bn.weight.grad.zero_()
+    bn.bias.grad.zero_()
+    dx_u = N.bn_backward(bn, st, got, None, nhwc(x_raw), False)
+    assert rel_err(dx_f, dx_u) < 1e-5 and rel_err(gw_f, bn.weight.grad) < 1e-5 and rel_err(gb_f, bn.bias.grad) < 1e-5
+
+
 @pytest.mark.parametrize("dims", [(2, 5, 7), (1, 128, 208)])
 def test_decoder_level_fused_upsample_concat(dims):
     """conv(cat(up2(a), skip)) with reflection padding: forward, wgrad, and the split/pooled dgrad.

@@ -109,6 +109,7 @@ struct IgemmParams {
     const float* addend;
     int pool;
     float* stats;
+    const float *stats_x, *stats_mean, *stats_invstd;      // BatchNorm-backward form of the statistics (mcav_igemm_desc.stats_x)
     int M;           // rows of the GEMM (incl. class / group padding)
     int Mc, McP;     // ADJ_STRIDE2: pixels per parity class and its BM-padded size; groups > 1: rows per group and padded size
     int groups;

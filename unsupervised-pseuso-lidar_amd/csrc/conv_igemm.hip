@@ -845,7 +845,7 @@ __global__ __launch_bounds__(256, (T::BM == 128 && T::BN == 64 && T::KD == 16 &&
     if (p.ksplit > 1) {      // raw partial tile into this split's y-shaped slab; bias / activation / aux factor / addend follow in splitk_finish_kernel
         IgemmParams q = p;
         q.y = p.kslab + (size_t)ks * ((size_t)p.g.B * p.Hd * p.Wd * p.Cd);
-        q.bias = nullptr; q.act = MCAV_ACT_NONE; q.dact_aux = nullptr; q.addend = nullptr; q.stats = nullptr;
+        q.bias = nullptr; q.act = MCAV_ACT_NONE; q.dact_aux = nullptr; q.addend = nullptr; q.stats = nullptr; q.stats_x = nullptr;
         igemm_epilogue_lean<T>(q, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
     } else {
         igemm_epilogue_lean<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
@@ -1761,6 +1761,8 @@ bool fill_params(const mcav_igemm_desc* d, IgemmParams& p, int& tile) {
     p.w = d->w; p.kh = d->kh; p.kw = d->kw; p.Kp = d->Kp; p.taps = d->kh * d->kw; p.Kstride = kstride_of(p.taps, d->Kp);
     p.y = d->y; p.Hd = d->Hd; p.Wd = d->Wd; p.Cd = d->Cd; p.n_begin = d->n_begin; p.n_count = d->n_count; p.y_choff = d->y_choff;
     p.bias = d->bias; p.act = d->act; p.dact_aux = d->dact_aux; p.dact = d->dact; p.addend = d->addend; p.pool = d->pool; p.stats = d->stats;
+    if (d->stats_x && (!d->stats || !d->stats_mean || !d->stats_invstd || d->pool || d->y_choff != 0 || d->n_begin != 0 || d->n_count != d->Cd)) return false;
+    p.stats_x = d->stats ? d->stats_x : nullptr; p.stats_mean = d->stats_mean; p.stats_invstd = d->stats_invstd;
     const long Mlin = (long)d->B * d->Hd * d->Wd;
     if ((long)d->B * d->Hs * d->Ws * (d->C1 > d->C2 ? d->C1 : d->C2) * 4 >= 0x7fffffffL) return false;   // 32-bit byte offsets
     if ((long)d->Np * kstride_of(d->kh * d->kw, d->Kp) * 4 >= 0x7fffffffL) return false;
@@ -1814,8 +1816,9 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         for (int k = 0; k < splits; ++k) v += slab[(size_t)k * n + i];
         if (bias) v += bias[n_begin + (int)(i % (size_t)Cd)];
         v = act_fwd(v, act);
-        if (dact_aux) v *= act_bwd(dact_aux[i], dact);
+        if (dact_aux && !(dact & MCAV_DACT_AFTER_ADDEND)) v *= act_bwd(dact_aux[i], dact & 0xff);
         if (addend) v += addend[i];
+        if (dact_aux && (dact & MCAV_DACT_AFTER_ADDEND)) v *= act_bwd(dact_aux[i], dact & 0xff);
         y[i] = v;
     }
 }

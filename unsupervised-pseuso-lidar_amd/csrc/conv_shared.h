@@ -139,8 +139,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, typename T:
                     if (o >= 0 && ncol) {
                         float s = (v[0] + v[1]) + (v[2] + v[3]);
                         const size_t off = (size_t)o * p.Cd + p.y_choff + nl;
-                        if (p.dact_aux) s *= act_bwd(p.dact_aux[off], p.dact);
+                        if (p.dact_aux && !(p.dact & MCAV_DACT_AFTER_ADDEND)) s *= act_bwd(p.dact_aux[off], p.dact & 0xff);
                         if (p.addend) s += p.addend[off];
+                        if (p.dact_aux && (p.dact & MCAV_DACT_AFTER_ADDEND)) s *= act_bwd(p.dact_aux[off], p.dact & 0xff);
                         p.y[off] = s;
                     }
                 } else {
@@ -150,11 +151,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, typename T:
                         if (o >= 0 && ncol) {
                             float s = v[e];
                             const size_t off = (size_t)o * p.Cd + p.y_choff + nl;
-                            if (p.dact_aux) s *= act_bwd(p.dact_aux[off], p.dact);
+                            if (p.dact_aux && !(p.dact & MCAV_DACT_AFTER_ADDEND)) s *= act_bwd(p.dact_aux[off], p.dact & 0xff);
                             if (p.addend) s += p.addend[off];
+                            if (p.dact_aux && (p.dact & MCAV_DACT_AFTER_ADDEND)) s *= act_bwd(p.dact_aux[off], p.dact & 0xff);
                             p.y[off] = s;
                             ssum[j] += s;
-                            ssq[j] += s * s;
+                            if (p.stats_x) {
+                                const int gi = (mt / (p.mtiles / p.groups)) * p.n_count + nl;
+                                ssq[j] += s * ((p.stats_x[off] - p.stats_mean[gi]) * p.stats_invstd[gi]);
+                            } else {
+                                ssq[j] += s * s;
+                            }
                         }
                     }
                 }
@@ -203,6 +210,8 @@ __device__ __forceinline__ void igemm_epilogue_lean(const IgemmParams& p, typena
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, ybytes);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.dact_aux ? p.dact_aux : p.y, ybytes);
     const __amdgpu_buffer_rsrc_t rad = make_rsrc(p.addend ? p.addend : p.y, ybytes);
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(p.stats_x ? p.stats_x : p.y, ybytes);
+    const int sgrp = p.stats_x ? (mt / (p.mtiles / p.groups)) * p.n_count : 0;      // this tile's group in stats_mean / stats_invstd
     float ssum[T::TN], ssq[T::TN];
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
@@ -237,8 +246,9 @@ __device__ __forceinline__ void igemm_epilogue_lean(const IgemmParams& p, typena
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = act_fwd(acc[i][j][4 * q + e] + bv, p.act);
                         float s = (v[0] + v[1]) + (v[2] + v[3]);
-                        if (p.dact_aux) s *= act_bwd(aux[q], p.dact);
+                        if (p.dact_aux && !(p.dact & MCAV_DACT_AFTER_ADDEND)) s *= act_bwd(aux[q], p.dact & 0xff);
                         if (p.addend) s += add[q];
+                        if (p.dact_aux && (p.dact & MCAV_DACT_AFTER_ADDEND)) s *= act_bwd(aux[q], p.dact & 0xff);
                         buf_store1(ry, ro[q].x + colb, s);
                     }
                 } else {
@@ -246,7 +256,16 @@ __device__ __forceinline__ void igemm_epilogue_lean(const IgemmParams& p, typena
                     constexpr int QH = NQ >= 2 ? NQ / 2 : 1;
 #pragma unroll
                     for (int q0 = 0; q0 < NQ; q0 += QH) {
-                        float aux[4 * QH], add[4 * QH];
+                        float aux[4 * QH], add[4 * QH], xs[4 * QH];
+                        float smu = 0.f, sis = 0.f;
+                        if (p.stats_x) {      // BatchNorm-backward statistics: the raw conv output of the layer being differentiated, its mean / invstd
+                            smu = p.stats_mean[sgrp + nl];
+                            sis = p.stats_invstd[sgrp + nl];
+#pragma unroll
+                            for (int q = 0; q < QH; ++q)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) xs[4 * q + e] = buf_load1(rsx, ro[q0 + q][e] + colb);
+                        }
                         if (p.dact_aux) {
 #pragma unroll
                             for (int q = 0; q < QH; ++q)
@@ -266,13 +285,14 @@ __device__ __forceinline__ void igemm_epilogue_lean(const IgemmParams& p, typena
                                 float s = acc[i][j][4 * (q0 + q) + e] + bv;
                                 if (p.act == MCAV_ACT_RELU) s = fmaxf(s, 0.f);
                                 else if (p.act != MCAV_ACT_NONE) s = act_fwd(s, p.act);
-                                if (p.dact_aux) s *= act_bwd(aux[4 * q + e], p.dact);
+                                if (p.dact_aux && !(p.dact & MCAV_DACT_AFTER_ADDEND)) s *= act_bwd(aux[4 * q + e], p.dact & 0xff);
                                 if (p.addend) s += add[4 * q + e];
+                                if (p.dact_aux && (p.dact & MCAV_DACT_AFTER_ADDEND)) s *= act_bwd(aux[4 * q + e], p.dact & 0xff);
                                 buf_store1(ry, ro[q0 + q][e] + colb, s);
                                 if (p.stats) {
                                     const float sv = ro[q0 + q][e] != OOB ? s : 0.f;
                                     ssum[j] += sv;
-                                    ssq[j] += sv * sv;
+                                    ssq[j] += p.stats_x ? sv * ((xs[4 * q + e] - smu) * sis) : sv * sv;
                                 }
                             }
                         __builtin_amdgcn_sched_barrier(0);

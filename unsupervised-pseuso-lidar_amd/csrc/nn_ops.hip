@@ -525,6 +525,13 @@ MCAV_EXPORT int mcav_bn_bwd_reduce(const float* dy, const float* y_act, const fl
     return launch_status();
 }
 
+MCAV_EXPORT int mcav_bn_bwd_finalize(const float* partial, int nblk, int C, float* dgamma, float* dbeta, int accumulate, float* sums, int groups, void* stream) {
+    if (groups < 1) groups = 1;
+    if (!partial || !sums || nblk <= 0 || C <= 0) return MCAV_E_INVALID;
+    bn_bwd_finalize_kernel<<<(C + 31) / 32, 32 * FIN_SL, 0, as_stream(stream)>>>(partial, nblk, C, dgamma, dbeta, accumulate, sums, groups);
+    return launch_status();
+}
+
 MCAV_EXPORT int mcav_bn_bwd_apply(const float* dy, const float* y_act, const float* x, const float* gamma, const float* save_mean,
                                   const float* save_invstd, const float* sums, int relu, size_t n_pix, int C, float* dx, float* dres,
                                   int dres_accumulate, int groups, void* stream) {

@@ -51,24 +51,41 @@ def block_forward(blk, x, stride, train, groups=1):
     return sv["out"], sv
 
 
-def block_backward(blk, sv, dout, addend=None):
+def block_backward(blk, sv, dout, addend=None, fused_in=None, consumer=None):
+    """fused_in: (slab, tiles per group) when `dout` already carries this block's bn2 ReLU mask and partial sums (produced by the previous
+    call's last data gradient).  consumer: saved tensors of the block that will receive this call's result, when that gradient may carry
+    ITS last BatchNorm's mask and partial sums (same stage, stride-1 first conv here) -> returns (dx, (slab, tiles per group))."""
     x, stride = sv["x"], sv["stride"]
     c1 = spec_of(blk.conv1, stride, 1, N.PAD_ZERO)
     c2 = spec_of(blk.conv2, 1, 1, N.PAD_ZERO)
-    dr2, dz = N.bn_backward(blk.bn2, sv["st2"], dout, sv["out"], sv["r2"], True, want_dres=True)
+    dr2, dz = N.bn_backward(blk.bn2, sv["st2"], dout, sv["out"], sv["r2"], True, want_dres=True, fused=fused_in)
     N.conv_wgrad(c2, sv["h1"], dr2)
-    dh1 = N.conv_dgrad(c2, dr2, hw(sv["h1"]))
-    dr1 = N.bn_backward(blk.bn1, sv["st1"], dh1, sv["h1"], sv["r1"], True)
+    if N.can_fuse_bn_stats(c2) and sv["st1"].mean is not None:
+        # dh1 arrives masked by ReLU'(h1) with bn1's backward partial sums in the epilogue's slab: no reduce pass over dh1 / h1 / r1
+        dh1, slab, mtg = N.conv_dgrad(c2, dr2, hw(sv["h1"]), dact_aux=sv["h1"], dact=N.ACT_RELU, bn_stats=(sv["r1"], sv["st1"]))
+        dr1 = N.bn_backward(blk.bn1, sv["st1"], dh1, None, sv["r1"], True, fused=(slab, mtg))
+    else:
+        dh1 = N.conv_dgrad(c2, dr2, hw(sv["h1"]))
+        dr1 = N.bn_backward(blk.bn1, sv["st1"], dh1, sv["h1"], sv["r1"], True)
     N.conv_wgrad(c1, x, dr1)
+    out_stats = None
+    kw = {}
+    if consumer is not None and N.can_fuse_bn_stats(c1) and consumer["st2"].mean is not None:
+        # the consumer's output ReLU masks the SUM of this gradient and the residual branch's (the addend)
+        kw = dict(dact_aux=consumer["out"], dact=N.ACT_RELU | N.DACT_AFTER_ADDEND, bn_stats=(consumer["r2"], consumer["st2"]))
     if blk.downsample is None:
         if addend is not None:
             dz = N.add(dz, addend)
-        return N.conv_dgrad(c1, dr1, hw(x), addend=dz)
-    cd = spec_of(blk.downsample[0], stride, 0, N.PAD_ZERO)
-    drd = N.bn_backward(blk.downsample[1], sv["std"], dz, None, sv["rd"], False)
-    N.conv_wgrad(cd, x, drd)
-    dxd = N.conv_dgrad(cd, drd, hw(x), addend=addend)
-    return N.conv_dgrad(c1, dr1, hw(x), addend=dxd)
+        res = N.conv_dgrad(c1, dr1, hw(x), addend=dz, **kw)
+    else:
+        cd = spec_of(blk.downsample[0], stride, 0, N.PAD_ZERO)
+        drd = N.bn_backward(blk.downsample[1], sv["std"], dz, None, sv["rd"], False)
+        N.conv_wgrad(cd, x, drd)
+        dxd = N.conv_dgrad(cd, drd, hw(x), addend=addend)
+        res = N.conv_dgrad(c1, dr1, hw(x), addend=dxd, **kw)
+    if kw:
+        return res[0], (res[1], res[2])
+    return res, None
 
 
 # ------------------------------------------------------------------------------------------------ Bottleneck (ResNet-50/101/152)
@@ -85,28 +102,45 @@ def bottleneck_forward(blk, x, stride, train, groups=1):
     return sv["out"], sv
 
 
-def bottleneck_backward(blk, sv, dout, addend=None):
+def bottleneck_backward(blk, sv, dout, addend=None, fused_in=None, consumer=None):
+    """As block_backward; the BatchNorms whose incoming gradient a stride-1 data gradient produces (bn2 after the 1x1 conv3, bn1 after a
+    stride-1 conv2, the consumer block's bn3 after this block's 1x1 conv1) take their backward partial sums from that launch's epilogue."""
     x, stride = sv["x"], sv["stride"]
     c1 = spec_of(blk.conv1, 1, 0, N.PAD_ZERO)
     c2 = spec_of(blk.conv2, stride, 1, N.PAD_ZERO)
     c3 = spec_of(blk.conv3, 1, 0, N.PAD_ZERO)
-    dr3, dz = N.bn_backward(blk.bn3, sv["st3"], dout, sv["out"], sv["r3"], True, want_dres=True)
+    dr3, dz = N.bn_backward(blk.bn3, sv["st3"], dout, sv["out"], sv["r3"], True, want_dres=True, fused=fused_in)
     N.conv_wgrad(c3, sv["h2"], dr3)
-    dh2 = N.conv_dgrad(c3, dr3, hw(sv["h2"]))
-    dr2 = N.bn_backward(blk.bn2, sv["st2"], dh2, sv["h2"], sv["r2"], True)
+    if N.can_fuse_bn_stats(c3) and sv["st2"].mean is not None:
+        dh2, slab, mtg = N.conv_dgrad(c3, dr3, hw(sv["h2"]), dact_aux=sv["h2"], dact=N.ACT_RELU, bn_stats=(sv["r2"], sv["st2"]))
+        dr2 = N.bn_backward(blk.bn2, sv["st2"], dh2, None, sv["r2"], True, fused=(slab, mtg))
+    else:
+        dh2 = N.conv_dgrad(c3, dr3, hw(sv["h2"]))
+        dr2 = N.bn_backward(blk.bn2, sv["st2"], dh2, sv["h2"], sv["r2"], True)
     N.conv_wgrad(c2, sv["h1"], dr2)
-    dh1 = N.conv_dgrad(c2, dr2, hw(sv["h1"]))
-    dr1 = N.bn_backward(blk.bn1, sv["st1"], dh1, sv["h1"], sv["r1"], True)
+    if N.can_fuse_bn_stats(c2) and sv["st1"].mean is not None:
+        dh1, slab, mtg = N.conv_dgrad(c2, dr2, hw(sv["h1"]), dact_aux=sv["h1"], dact=N.ACT_RELU, bn_stats=(sv["r1"], sv["st1"]))
+        dr1 = N.bn_backward(blk.bn1, sv["st1"], dh1, None, sv["r1"], True, fused=(slab, mtg))
+    else:
+        dh1 = N.conv_dgrad(c2, dr2, hw(sv["h1"]))
+        dr1 = N.bn_backward(blk.bn1, sv["st1"], dh1, sv["h1"], sv["r1"], True)
     N.conv_wgrad(c1, x, dr1)
+    kw = {}
+    if consumer is not None and N.can_fuse_bn_stats(c1) and consumer["st3"].mean is not None:
+        kw = dict(dact_aux=consumer["out"], dact=N.ACT_RELU | N.DACT_AFTER_ADDEND, bn_stats=(consumer["r3"], consumer["st3"]))
     if blk.downsample is None:
         if addend is not None:
             dz = N.add(dz, addend)
-        return N.conv_dgrad(c1, dr1, hw(x), addend=dz)
-    cd = spec_of(blk.downsample[0], stride, 0, N.PAD_ZERO)
-    drd = N.bn_backward(blk.downsample[1], sv["std"], dz, None, sv["rd"], False)
-    N.conv_wgrad(cd, x, drd)
-    dxd = N.conv_dgrad(cd, drd, hw(x), addend=addend)
-    return N.conv_dgrad(c1, dr1, hw(x), addend=dxd)
+        res = N.conv_dgrad(c1, dr1, hw(x), addend=dz, **kw)
+    else:
+        cd = spec_of(blk.downsample[0], stride, 0, N.PAD_ZERO)
+        drd = N.bn_backward(blk.downsample[1], sv["std"], dz, None, sv["rd"], False)
+        N.conv_wgrad(cd, x, drd)
+        dxd = N.conv_dgrad(cd, drd, hw(x), addend=addend)
+        res = N.conv_dgrad(c1, dr1, hw(x), addend=dxd, **kw)
+    if kw:
+        return res[0], (res[1], res[2])
+    return res, None
 
 
 # ------------------------------------------------------------------------------------------------ encoder
@@ -138,12 +172,15 @@ def encoder_backward(net, sv, dfeats, complete=False):
     complete: this call produces the parameters' whole gradient (stacked passes): stages are announced to N.grads_ready."""
     feats = sv["feats"]
     dcur = dfeats[4]
+    fused = None            # (slab, tiles per group) when dcur already carries the next block's output mask and BatchNorm partial sums
     for si in range(3, -1, -1):
         blks = list(getattr(net, STAGES[si]))
         for bi in range(len(blks) - 1, -1, -1):
             addend = dfeats[si] if (bi == 0 and si > 0) else None      # skip-connection gradient of this stage's input
             bwd = bottleneck_backward if hasattr(blks[bi], "conv3") else block_backward
-            dcur = bwd(blks[bi], sv["blocks"][si][bi], dcur, addend)
+            # the block that receives this call's result (same stage: nothing else adds to that gradient) may take it masked and summed
+            consumer = sv["blocks"][si][bi - 1] if bi > 0 else None
+            dcur, fused = bwd(blks[bi], sv["blocks"][si][bi], dcur, addend, fused_in=fused, consumer=consumer)
         if complete and N.GRADS_READY is not None:       # layer4 holds half of all parameters and finishes first: its all-reduce hides behind layers 3..1
             from .dist import announced_stages
             if STAGES[si] in announced_stages():

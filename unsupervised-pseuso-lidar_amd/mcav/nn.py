@@ -15,6 +15,7 @@ c_p, c_i, c_f, c_sz, c_d = L.c_p, L.c_i, L.c_f, L.c_sz, ctypes.c_double
 G_DIRECT, G_SMALLC, G_ADJ_REFLECT, G_ADJ_STRIDE2 = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
+DACT_AFTER_ADDEND = 0x100       # (conv + addend) * act'(aux) instead of conv * act'(aux) + addend
 
 
 class IgemmDesc(ctypes.Structure):
@@ -23,7 +24,8 @@ class IgemmDesc(ctypes.Structure):
                 ("mode", c_i), ("stride", c_i), ("sign", c_i), ("offset", c_i), ("pad_mode", c_i),
                 ("y", c_p), ("Hd", c_i), ("Wd", c_i), ("Cd", c_i), ("n_begin", c_i), ("n_count", c_i), ("y_choff", c_i),
                 ("bias", c_p), ("act", c_i), ("dact_aux", c_p), ("dact", c_i), ("addend", c_p), ("pool", c_i), ("stats", c_p),
-                ("tile", c_i), ("groups", c_i), ("w_upmerge", c_p), ("mma", c_i), ("w16", c_p), ("w_stem", c_p)]
+                ("tile", c_i), ("groups", c_i), ("w_upmerge", c_p), ("mma", c_i), ("w16", c_p),
+                ("stats_x", c_p), ("stats_mean", c_p), ("stats_invstd", c_p), ("w_stem", c_p)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -70,6 +72,7 @@ L.register({
     "mcav_bn_bwd_workspace_bytes": (c_sz, [c_sz, c_i, c_i]),
     "mcav_bn_bwd_reduce": (c_i, [c_p] * 5 + [c_i, c_sz, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_sz, c_p]),
     "mcav_bn_bwd_apply": (c_i, [c_p] * 7 + [c_i, c_sz, c_i, c_p, c_p, c_i, c_i, c_p]),
+    "mcav_bn_bwd_finalize": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
     "mcav_maxpool3s2_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     "mcav_maxpool3s2_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "mcav_act_bwd": (c_i, [c_p, c_p, c_i, c_sz, c_p, c_i, c_p]),
@@ -397,11 +400,22 @@ def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0, gr
     return (y, slab) if stats else y
 
 
-def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=None, dact=ACT_NONE, addend=None, pool=False, tile=0):
+BN_BWD_FUSE = _os.environ.get("MCAV_BN_BWD_FUSE", "1") != "0"      # BatchNorm-backward column sums in the epilogue of the dgrad that produces dy
+
+
+def can_fuse_bn_stats(spec):
+    """The data gradient of `spec` can carry the BatchNorm-backward statistics of the layer it feeds (mcav_igemm_desc.stats_x): a stride-1
+    zero-padded convolution (the DIRECT gather keeps the groups of a stacked pass apart)."""
+    return BN_BWD_FUSE and spec.stride == 1 and spec.pad_mode == PAD_ZERO
+
+
+def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=None, dact=ACT_NONE, addend=None, pool=False, tile=0, bn_stats=None):
     """Gradient w.r.t. the (logical, concatenated) conv input, channels [n_begin, n_begin + n_count).
 
     dy: [B, Hd, Wd, Cout] gradient at the conv output (pre-activation).  in_shape = (Hs, Ws) of the logical input.
-    Epilogue: 2x2 sum pooling (pool), * act'(dact_aux), + addend.  Returns [B, Hs(/2), Ws(/2), n_count]."""
+    Epilogue: 2x2 sum pooling (pool), * act'(dact_aux), + addend.  Returns [B, Hs(/2), Ws(/2), n_count].
+    bn_stats = (x_raw, BNState): the result is the gradient arriving at a train-mode BatchNorm whose raw input was x_raw; the epilogue also
+    leaves that BatchNorm's backward partial sums (sum g, sum g * xhat per tile and channel) in a slab -> returns (y, slab, tiles per group)."""
     B, Hd, Wd, Cout = dy.shape
     Hs, Ws = in_shape
     if n_count is None:
@@ -430,10 +444,24 @@ def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=N
     d.dact_aux, d.dact, d.addend, d.pool = P(dact_aux), dact, P(addend), int(pool)
     d.tile = tile
     _weights_for(spec, d, True)
+    slab = None
+    if bn_stats is not None:
+        x_raw, st = bn_stats
+        if pool or n_begin != 0 or n_count != y.shape[3] or tuple(x_raw.shape) != tuple(y.shape) or st.mean is None:
+            raise L.MCAVError("conv_dgrad: bn_stats needs an un-pooled, whole-width gradient of the BatchNorm input's shape")
+        d.groups = st.groups
+        d.stats_x, d.stats_mean, d.stats_invstd = P(x_raw), P(st.mean), P(st.invstd)
+        d.stats = d.x1                                  # (placeholder: the tile count does not depend on it)
+        mt = L.lib().mcav_igemm_mtiles(ctypes.byref(d))
+        if mt <= 0 or mt % st.groups:
+            raise L.MCAVError("mcav_igemm_mtiles: invalid descriptor (%d)" % mt)
+        slab = empty((mt, 2, n_count), dy)
+        d.stats = P(slab)
     with _Timed("dgrad", 2.0 * B * Hd * Wd * spec.cout * n_count * spec.kh * spec.kw,
-                "M=%d N=%d K=%dx%d s%d mode%d pool%d %dx%d" % (B * Hs * Ws, n_count, Cout, spec.kh * spec.kw, spec.stride, d.mode, int(pool), Hs, Ws)):
+                "M=%d N=%d K=%dx%d s%d mode%d pool%d %dx%d%s" % (B * Hs * Ws, n_count, Cout, spec.kh * spec.kw, spec.stride, d.mode, int(pool), Hs, Ws,
+                                                                " +bn-bwd stats" if slab is not None else "")):
         L.check(L.lib().mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(dgrad)")
-    return y
+    return y if slab is None else (y, slab, slab.shape[0] // bn_stats[1].groups)
 
 
 import os as _os
@@ -762,12 +790,27 @@ def bn_apply(x, st, relu, residual=None):
     return y
 
 
-def bn_backward(bn, st, dy, y_act, x, relu, want_dres=False, dres_out=None, dres_accumulate=False):
-    """-> dx (and dz, the masked incoming gradient, when want_dres).  Accumulates dgamma/dbeta into .grad."""
+def bn_backward(bn, st, dy, y_act, x, relu, want_dres=False, dres_out=None, dres_accumulate=False, fused=None):
+    """-> dx (and dz, the masked incoming gradient, when want_dres).  Accumulates dgamma/dbeta into .grad.
+    fused = (slab, tiles per group): dy comes from a data gradient that already applied the ReLU mask and left this BatchNorm's partial sums
+    in `slab` (conv_dgrad(bn_stats=...)): the reduce pass over dy / the activations / x is skipped, and so is the mask in the apply pass."""
     C = x.shape[-1]
     n_pix = x.numel() // C
     h = L.lib()
     G = st.groups
+    if fused is not None:
+        slab, mtg = fused
+        sums = empty((G, 2, C), x)
+        gg, gb = grad_buffer(bn.weight), grad_buffer(bn.bias)
+        L.check(h.mcav_bn_bwd_finalize(P(slab), mtg, C, P(gg), P(gb), 1, P(sums), G, L.stream()), "mcav_bn_bwd_finalize")
+        dx = torch.empty_like(x)
+        L.check(h.mcav_bn_bwd_apply(P(dy), None, P(x), P(bn.weight), P(st.mean), P(st.invstd), P(sums), 0, n_pix, C, P(dx), None, 0, G, L.stream()),
+                "mcav_bn_bwd_apply")
+        if want_dres:
+            if dres_out is not None:
+                raise L.MCAVError("bn_backward: a fused gradient is its own residual gradient (no dres_out)")
+            return dx, dy                       # the masked incoming gradient IS dy
+        return dx
     ws = L.workspace(h.mcav_bn_bwd_workspace_bytes(n_pix, C, G), x.device, "bn_bwd")
     sums = empty((G, 2, C), x)
     gg, gb = grad_buffer(bn.weight), grad_buffer(bn.bias)
