@@ -5,6 +5,8 @@ torch tensors ([B, H, W, C]); parameters keep the reference's shapes (OIHW conv 
 interchangeable, and are re-packed to the kernels' [Np][taps][Kp] form whenever they change.
 """
 import ctypes
+import os
+import os as _os
 
 import torch
 
@@ -464,7 +466,6 @@ def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=N
     return y if slab is None else (y, slab, slab.shape[0] // bn_stats[1].groups)
 
 
-import os as _os
 UPMERGE_ADJ_MIN_N = int(_os.environ.get("MCAV_UPMERGE_ADJ_MIN_N", "32"))       # narrower outputs: the halo-tile adjoint kernel is faster
 
 
@@ -683,7 +684,6 @@ class _WgradBatch:
             L.check(h.mcav_wgrad_reduce_multi(P(table), n, npb, nrb, nlds, L.stream()), "mcav_wgrad_reduce_multi")
 
 
-import os
 WGRAD_BATCH = _WgradBatch()
 
 
