@@ -645,7 +645,7 @@ class _WgradBatch:
     """Weight-gradient slab reductions of a gradient bucket as ONE presum + ONE reduce launch (mcav_wgrad_deferred / mcav_wgrad_reduce_multi).
     Inside a backward pass every weight-gradient GEMM leaves its slab in its own buffer (the k-th pending launch uses pool[k]: the launch
     sequence of a step is static, so the buffers and therefore the device tables are the same every step -- a table is built once per
-    launch sequence).  Outside a backward pass (direct calls, the instrumented steps of bench.py) the per-layer launches run."""
+    launch sequence).  Outside a backward pass (direct calls, micro-benchmarks) the per-layer launches run."""
 
     def __init__(self):
         self.enabled = os.environ.get("MCAV_WGRAD_BATCH", "1") != "0"
@@ -695,7 +695,7 @@ def launch_wgrad(d, tensors, flops=0.0, tag="", executed=None):
         raise L.MCAVError("mcav_wgrad: invalid descriptor")
 
     dev = tensors[0].device
-    defer = WGRAD_BATCH.enabled and PROFILE is None and dev.type == "cuda" and WGRAD_SIDE._note(torch.cuda.current_stream())
+    defer = WGRAD_BATCH.enabled and dev.type == "cuda" and WGRAD_SIDE._note(torch.cuda.current_stream())
     if defer:
         # inside a backward pass: GEMM now, the slab reduction with its bucket (grads_ready / the end-of-backward join).  The descriptor is
         # copied: the caller re-uses `d` for its next launch.
