@@ -73,6 +73,8 @@ def measured_traffic(steps_in_profile=3):
 
 
 def workload_label(B, H, W, layers, ssim, dtype="fp32"):
+    if dtype == "fp32-split":
+        return "fp32-split variant of " + workload_label(B, H, W, layers, ssim)
     if dtype == "bf16":
         if (B, H, W, layers, ssim) == (12, 192, 640, 18, False):
             return "BASELINE.json configs[2] per-GPU shape"
@@ -101,8 +103,8 @@ def build(device, lr=1e-4, seed=0, depth_layers=18, ssim=False, dtype="fp32"):
     from mcav.optim import FusedAdam
     from losses import Losses
     torch.manual_seed(seed)
-    depth = DispResNet(depth_layers, dtype=torch.bfloat16 if dtype == "bf16" else None)      # bf16: the conv tiles of the depth net (98 % of the FLOPs)
-    pose = PoseNet()
+    depth = DispResNet(depth_layers, dtype=torch.bfloat16 if dtype == "bf16" else "fp32-split" if dtype == "fp32-split" else None)      # bf16: the conv tiles of the depth net (98 % of the FLOPs)
+    pose = PoseNet(dtype="fp32-split") if dtype == "fp32-split" else PoseNet()
     pose.init_weights()
     depth.to(device).train()
     pose.to(device).train()
@@ -193,9 +195,10 @@ def main():
     ap.add_argument("--depth-layers", type=int, default=18, help="ResNet depth of the encoder (18 = the metric's config; 50 = BASELINE.json configs[3])")
     ap.add_argument("--ssim", action="store_true", help="photometric term = 0.85 SSIM + 0.15 L1 (Losses(ssim=True); BASELINE.json configs[3] "
                                                         "stresses this kernel) instead of the reference's live L1")
-    ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32",
+    ap.add_argument("--dtype", choices=("fp32", "bf16", "fp32-split"), default="fp32",
                     help="bf16: the depth net's conv tiles on the bf16 MFMA (BASELINE.json configs[2] / [4]; fp32 accumulation, fp32 master weights and "
-                         "activations in HBM); the headline metric is quoted on fp32")
+                         "activations in HBM); fp32-split: fp32 contractions carried by the bf16 MFMA (three bf16 planes per operand, six plane "
+                         "products, fp32 accumulation: fp32 results); the headline metric is quoted on fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--separate-passes", action="store_true", help="run the two depth passes as separate launch sets (default: stacked)")
@@ -282,11 +285,13 @@ def main():
 
     out = {"metric": "images/sec (fwd+bwd) KITTI 192x640 triplets, full training step", "value": round(value, 3), "unit": "images/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp32-split": "f32 (operands as three bf16 planes, six bf16-MFMA products, fp32 accumulate)"}[args.dtype],
+           "data": "synthetic",
            "config": {"workload": "%s: per-GPU batch=%d, %dx%d KITTI-shaped triplets, ResNet-%d depth encoder + 6-DoF PoseNet, "
                                   "%s, one step = 2x depth fwd + pose fwd + warp/%s/smooth loss + backward + Adam%s" %
                                   (workload_label(B, H, W, args.depth_layers, args.ssim, args.dtype),
-                                   B, H, W, args.depth_layers, "fp32" if args.dtype == "fp32" else "bf16 MFMA conv tiles (fp32 accumulate / storage)",
+                                   B, H, W, args.depth_layers, {"fp32": "fp32", "bf16": "bf16 MFMA conv tiles (fp32 accumulate / storage)",
+                                                                "fp32-split": "fp32 (contractions on the bf16 MFMA over split operands)"}[args.dtype],
                                    "SSIM+L1" if args.ssim else "L1", " + 1 RCCL all-reduce of the gradient arena" if world > 1 else ""),
                       "global_batch": B * world, "parallelism": "dp%d" % world},
            "loss": [round(float(l.detach()), 6) for l in loss], "hipgraph": bool(getattr(make_step, "graphed", False)),
@@ -343,7 +348,7 @@ def main():
         conv_traffic, warp_traffic = measured_traffic() if (B, H, W) == (12, 192, 640) else (None, None)
         if args.ssim:
             warp_traffic = None
-        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         if args.dtype != "fp32":
             conv_traffic = None
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",

@@ -75,9 +75,16 @@ typedef struct mcav_igemm_desc {
     int mma;                /* 0 = fp32 MFMA (exact fp32 products).  1 = bf16 MFMA tiles (BASELINE.json configs[2] / [4]): the source pixels are
                              * rounded to bf16 on their way into LDS, the filter comes from w16, accumulation / epilogue / outputs stay fp32.
                              * Launches the bf16 kernels do not cover (image stem, narrow high-resolution layers, 1-channel heads, pooled and
-                             * merged-tap forms) run the fp32 kernels with w; mcav_igemm_uses_bf16() tells which. */
+                             * merged-tap forms) run the fp32 kernels with w; mcav_igemm_uses_bf16() tells which.
+                             * 2 = the fp32 contraction carried by the bf16 MFMA (round 3): every operand element is split into three bf16 planes
+                             * a = h + m + l (h = bf16(a), m = bf16(a - h), l = bf16(a - h - m); the remainder is below 2^-26 |a|) and the six plane
+                             * products hh, hm, mh, hl, lh, mm are accumulated in fp32 (dropped: ml, lm, ll <= 2^-26 of a product).  Same launches
+                             * as mma = 1, result at least as exact as the fp32 MFMA's (profiles/r03_mfma_split_exactness.txt) at 6 / 16 of its
+                             * MFMA time. */
     const void* w16;        /* mma = 1: bf16 copy of the packed filter, same [Np][kh*kw][Kp] layout and row stride in ELEMENTS
-                             * (mcav_pack_weights_multi with transposed | 2, or mcav_f32_to_bf16 of a packed fp32 copy) */
+                             * (mcav_pack_weights_multi with transposed | 2, or mcav_f32_to_bf16 of a packed fp32 copy).
+                             * mma = 2: three such copies back to back, the planes h, m, l of the packed filter, Np * Kstride elements each
+                             * (mcav_pack_weights_multi with transposed | 4, or mcav_f32_to_bf16_planes of a packed fp32 copy) */
     /* BatchNorm BACKWARD statistics in the epilogue of the data gradient that produces dy (round 3; with `stats`): when stats_x is set the
      * second statistic of a column is the sum of y * xhat, xhat = (stats_x - stats_mean[g][n]) * stats_invstd[g][n], instead of the sum of
      * y^2 -- y being what the epilogue stores (after the act'(dact_aux) factor and the addend), stats_x the raw output of the convolution
@@ -94,7 +101,7 @@ typedef struct mcav_igemm_desc {
 /* number of M-tiles (rows of `stats`) the launch will use with its chosen tile config */
 int mcav_igemm_mtiles(const mcav_igemm_desc* d);
 int mcav_igemm(const mcav_igemm_desc* d, void* stream);
-int mcav_igemm_uses_bf16(const mcav_igemm_desc* d);      /* 1: this descriptor (mma = 1, w16 set) runs on the bf16 MFMA kernels */
+int mcav_igemm_uses_bf16(const mcav_igemm_desc* d);      /* 1: this descriptor (mma = 1 or 2, w16 set) runs on the bf16 MFMA kernels */
 
 /* Weight gradient: dw[n][tap][c] = sum_pix dy[pix, n] * src(pix, tap)[c], reduced over pixel splits and written
  * (accumulated if accumulate != 0) in OIHW [Cout][Cin][kh][kw] to dw_oihw.  The source is gathered exactly as in
@@ -121,7 +128,8 @@ typedef struct mcav_wgrad_desc {
      *    NULL (the skip launch carries it).  Same result as one ordinary launch up to fp32 summation order. */
     int upm, Cin_total, ci_offset;
     int mma;                /* 1: both operands rounded to bf16, reduction over pixels on the bf16 MFMA, fp32 slab / gradient (launches with
-                             * >= 32 output channels and 16-channel-aligned sources; others run the fp32 kernels) */
+                             * >= 32 output channels and 16-channel-aligned sources; others run the fp32 kernels).
+                             * 2: the same launches as an fp32 contraction on three bf16 planes per operand (mcav_igemm_desc.mma = 2) */
 } mcav_wgrad_desc;
 
 size_t mcav_wgrad_workspace_bytes(const mcav_wgrad_desc* d);
@@ -159,9 +167,12 @@ int mcav_pack_weights(const float* w_oihw, int Cout, int Cin, int kh, int kw, in
  * preceding records; nblocks = that sum over all records. */
 int mcav_pack_weights_multi(const void* items_dev, int nitems, int nblocks, void* stream);
 /* A record whose `transposed` has bit 1 set (2 or 3) writes its packed copy as bf16 (same layout, 2-byte elements): the filter copies
- * of the bf16 MFMA kernels, re-derived from the fp32 master weights after every optimiser step in the same launch. */
+ * of the bf16 MFMA kernels, re-derived from the fp32 master weights after every optimiser step in the same launch.  Bit 2 (4 or 5): as
+ * three bf16 planes h, m, l of Np * Kstride elements each (mcav_igemm_desc.mma = 2). */
 /* round-to-nearest-even fp32 -> bf16 of a flat buffer (the special packed copies: merged-tap adjoint filters) */
 int mcav_f32_to_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
+/* dst[0 .. n) = h, dst[n .. 2n) = m, dst[2n .. 3n) = l with src = h + m + l up to 2^-26 |src| (the filter planes of mma = 2) */
+int mcav_f32_to_bf16_planes(const float* src, void* dst_bf16, size_t n, void* stream);
 int mcav_pack_weights_blocks(int taps, int transposed, int Np, int Kp);   /* workgroups one record needs */
 /* A 7x7 stride-2 stem filter -- the depth net's conv1 (reference resnet_dispnet.py:38: torchvision resnet, OIHW [64][3][7][7]) or PoseNet's
  * conv1 (pose_net.py:40: [16][9][7][7]) -- in the K order of the patch-in-LDS kernels: [Cin * 56][Cout], row ((c * 7 + ky) * 4 + j) * 2 + h =

@@ -61,6 +61,7 @@ def main():
         w = torch.nn.Parameter(torch.randn(Cout, Cin, k, k, device=dev) * 0.05)
         b = torch.nn.Parameter(torch.zeros(Cout, device=dev))
         spec = N.ConvSpec(w, b, s, p, pm)
+        spec.mma = int(os.environ.get("CONV_BENCH_MMA", "0"))      # 1: bf16 MFMA tiles, 2: fp32 on split operands (where the launch qualifies)
         x = torch.randn(B, H, W, Cin, device=dev)
         Ho, Wo = N.out_size(H, k, s, p), N.out_size(W, k, s, p)
         dy = torch.randn(B, Ho, Wo, Cout, device=dev)

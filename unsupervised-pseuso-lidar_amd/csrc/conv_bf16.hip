@@ -59,12 +59,21 @@ __device__ __forceinline__ u32x2 pack_bf16x4(f32x4 v) {
 // TK = 0: DIRECT gathers (zero / reflection padding, stride 1 / 2, fused upsample + concat) and the stride-2 adjoint;
 // TK = 1: the adjoint of the 3x3 reflection-padded conv (border wavefronts add up to three reflected sources per row, in fp32, before the
 //         rounding to bf16).  Prologue (row decode, tap list, offset tables) as igemm_tab_kernel.
-template <class T, int TK>
+//
+// NS = 1: operands rounded to bf16 (mma = 1).  NS = 3: an fp32 contraction on the bf16 MFMA (mma = 2): each operand element is split into
+// three bf16 planes a = h + m + l (h = bf16(a), m = bf16(a - h), l = bf16(a - h - m), round to nearest: what is left is below 2^-26 |a|),
+// the filter planes come pre-split from the packed copy, and the six plane products hh, hm, mh, hl, lh, mm are accumulated in fp32 (dropped:
+// ml, lm, ll <= 2^-26 of a product, under the rounding of one fp32 multiply-add); the products below hh go into accumulators of their own
+// and are added once at the end.  Measured against float64 (tools/mfma_split_test.hip, profiles/r03_mfma_split_exactness.txt): the result
+// is at least as exact as v_mfma_f32_32x32x2_f32 on the unsplit operands, at 6 / 16 of its MFMA time.  The planes triple the LDS panel, so
+// the split form keeps ONE panel (two barriers per K-tile; the other workgroups of the CU cover them).
+template <class T, int TK, int NS>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p, const u16* __restrict__ w16) {
     constexpr bool REFL = TK == 1;
     constexpr int BM = T::BM, BN = T::BN, CKT = T::KD;
-    __shared__ __attribute__((aligned(16))) u16 As[2][BM][T::LDH];
-    __shared__ __attribute__((aligned(16))) u16 Bs[2][BN][T::LDH];
+    constexpr int NB = NS == 1 ? 2 : 1;                           // LDS panels; indexed [NB * NS]: buffer b of the plain form = plane 0 of panel b
+    __shared__ __attribute__((aligned(16))) u16 As[NB * NS][BM][T::LDH];
+    __shared__ __attribute__((aligned(16))) u16 Bs[NB * NS][BN][T::LDH];
     __shared__ int s_out[BM];
     float (*const s_stat)[2][BN] = reinterpret_cast<float (*)[2][BN]>(&As[1][0][0]);
     static_assert(sizeof(u16) * BM * T::LDH >= sizeof(float) * T::WAVES_M * 2 * BN, "statistics scratch fits one A buffer");
@@ -141,7 +150,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p, const u1
     const unsigned bytes2 = (unsigned)((size_t)g.B * g.Hs * g.Ws * g.C2 * 4);
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1, bytes1);
     const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(g.C2 > 0 ? g.x2 : g.x1, g.C2 > 0 ? bytes2 : 0u);
-    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(w16, (unsigned)((size_t)(p.n_begin + p.n_count) * p.Kstride * 2));
+    const unsigned plane_bytes = (unsigned)((size_t)p.Np_all * p.Kstride * 2);      // NS = 3: plane q of the filter starts q * plane_bytes further
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(w16, (unsigned)((size_t)(p.n_begin + p.n_count) * p.Kstride * 2) + (NS - 1) * plane_bytes);
 
     const int c4 = tid % T::LPRA, r0 = tid / T::LPRA;
     unsigned boff[T::BVECS];
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p, const u1
         }
         wave_border = __any(bd);
     }
-    f32x4 ex0[REFL ? T::AROWS : 1], ex1[REFL ? T::AROWS : 1], ex2[REFL ? T::AROWS : 1];
+    constexpr int EXR = REFL ? T::AROWS : 1;                     // a register stage's reflected border sources
     int ti = 0, chunk = 0;
     int tap = __builtin_amdgcn_readfirstlane(s_tl[0]);
     unsigned oa[T::AROWS], ob[T::AROWS];
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p, const u1
         }
     };
     refresh();
-    auto issue = [&](f32x4 (&ra)[T::AROWS], f32x4 (&rb)[T::BVECS]) {
+    auto issue = [&](f32x4 (&ra)[T::AROWS], f32x4 (&rb)[NS][T::BVECS], f32x4 (&ex)[3][EXR]) {
         const int cbase = chunk * CKT;
         if (cbase < g.C1) {
 #pragma unroll
@@ -192,21 +202,23 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p, const u1
                     const int n = s_rn[r], dy = s_ry[r], dx = s_rx[r];
                     const int sy = dy + 1 - ky, sx = dx + 1 - kx;
                     const int ey = (dy == 1 && ky == 0) ? 0 : ((dy == g.Hs - 2 && ky == 2) ? g.Hs - 1 : -1);
-                    const int ex = (dx == 1 && kx == 0) ? 0 : ((dx == g.Ws - 2 && kx == 2) ? g.Ws - 1 : -1);
+                    const int exx = (dx == 1 && kx == 0) ? 0 : ((dx == g.Ws - 2 && kx == 2) ? g.Ws - 1 : -1);
                     const bool syok = (unsigned)sy < (unsigned)g.Hs, sxok = (unsigned)sx < (unsigned)g.Ws;
                     const int rowb = n * g.Hs, cb = c4 * 4;
                     const unsigned a0 = (unsigned)((((rowb + ey) * g.Ws + sx) * g.C1 + cb) * 4);
-                    const unsigned a1 = (unsigned)((((rowb + sy) * g.Ws + ex) * g.C1 + cb) * 4);
-                    const unsigned a2 = (unsigned)((((rowb + ey) * g.Ws + ex) * g.C1 + cb) * 4);
-                    ex0[j] = buf_load4s(rs1, (n >= 0 && ey >= 0 && sxok) ? a0 : OOB, cbase * 4);
-                    ex1[j] = buf_load4s(rs1, (n >= 0 && ex >= 0 && syok) ? a1 : OOB, cbase * 4);
-                    ex2[j] = buf_load4s(rs1, (n >= 0 && ey >= 0 && ex >= 0) ? a2 : OOB, cbase * 4);
+                    const unsigned a1 = (unsigned)((((rowb + sy) * g.Ws + exx) * g.C1 + cb) * 4);
+                    const unsigned a2 = (unsigned)((((rowb + ey) * g.Ws + exx) * g.C1 + cb) * 4);
+                    ex[0][j] = buf_load4s(rs1, (n >= 0 && ey >= 0 && sxok) ? a0 : OOB, cbase * 4);
+                    ex[1][j] = buf_load4s(rs1, (n >= 0 && exx >= 0 && syok) ? a1 : OOB, cbase * 4);
+                    ex[2][j] = buf_load4s(rs1, (n >= 0 && ey >= 0 && exx >= 0) ? a2 : OOB, cbase * 4);
                 }
             }
         }
         const int kb = (tap * p.Kp + cbase) * 2;
 #pragma unroll
-        for (int j = 0; j < T::BVECS; ++j) rb[j] = buf_load4s(rsw, boff[j], kb);
+        for (int q = 0; q < NS; ++q)
+#pragma unroll
+            for (int j = 0; j < T::BVECS; ++j) rb[q][j] = buf_load4s(rsw, boff[j], kb + q * (int)plane_bytes);
         if (++chunk == nchunks) {
             chunk = 0;
             ++ti;
@@ -215,49 +227,80 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p, const u1
         }
     };
     constexpr bool BFULL = (BN * T::LPRB) % 256 == 0;
-    auto store = [&](f32x4 (&ra)[T::AROWS], const f32x4 (&rb)[T::BVECS], auto bufc) {
-        constexpr int buf = decltype(bufc)::value;
+    auto store = [&](f32x4 (&ra)[T::AROWS], const f32x4 (&rb)[NS][T::BVECS], const f32x4 (&ex)[3][EXR], auto bufc) {
+        constexpr int buf = decltype(bufc)::value * NS;
 #pragma unroll
         for (int j = 0; j < T::AROWS; ++j) {
             if constexpr (REFL) {
-                if (wave_border) ra[j] += (ex0[j] + ex1[j]) + ex2[j];
+                if (wave_border) ra[j] += (ex[0][j] + ex[1][j]) + ex[2][j];
             }
-            *reinterpret_cast<u32x2*>(&As[buf][r0 + T::RPPA * j][c4 * 4]) = pack_bf16x4(ra[j]);
+            if constexpr (NS == 1) {
+                *reinterpret_cast<u32x2*>(&As[buf][r0 + T::RPPA * j][c4 * 4]) = pack_bf16x4(ra[j]);
+            } else {
+                const bf16x4 h = __builtin_convertvector(ra[j], bf16x4);
+                const f32x4 r1 = ra[j] - __builtin_convertvector(h, f32x4);            // exact
+                const bf16x4 m = __builtin_convertvector(r1, bf16x4);
+                const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);               // exact
+                *reinterpret_cast<u32x2*>(&As[buf][r0 + T::RPPA * j][c4 * 4]) = __builtin_bit_cast(u32x2, h);
+                *reinterpret_cast<u32x2*>(&As[buf + 1][r0 + T::RPPA * j][c4 * 4]) = __builtin_bit_cast(u32x2, m);
+                *reinterpret_cast<u32x2*>(&As[buf + 2][r0 + T::RPPA * j][c4 * 4]) = pack_bf16x4(r2);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < T::BVECS; ++j) {
-            const int e = tid + 256 * j, nn = e / T::LPRB, cb = e % T::LPRB;
-            if (BFULL || nn < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nn][cb * 8]) = rb[j];
-        }
+        for (int q = 0; q < NS; ++q)
+#pragma unroll
+            for (int j = 0; j < T::BVECS; ++j) {
+                const int e = tid + 256 * j, nn = e / T::LPRB, cb = e % T::LPRB;
+                if (BFULL || nn < BN) *reinterpret_cast<f32x4*>(&Bs[buf + q][nn][cb * 8]) = rb[q][j];
+            }
     };
 
     const int wm0 = (wave / T::WAVES_N) * T::WM, wn0 = (wave % T::WAVES_N) * T::WN;
     typename T::AccT acc[T::TM][T::TN];
+    typename T::AccT mid[NS == 1 ? 1 : T::TM][NS == 1 ? 1 : T::TN], low[NS == 1 ? 1 : T::TM][NS == 1 ? 1 : T::TN];      // mh + hm; lh + hl + mm
 #pragma unroll
     for (int i = 0; i < T::TM; ++i)
 #pragma unroll
         for (int j = 0; j < T::TN; ++j)
 #pragma unroll
-            for (int r = 0; r < T::ACC; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < T::ACC; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (NS > 1) { mid[i][j][r] = 0.f; low[i][j][r] = 0.f; }
+            }
 
     constexpr int MFR = T::MF;
     constexpr int KSTEP = MFR == 32 ? 16 : 32;                     // k per MFMA
     const int frow = lane & (MFR - 1), fk = (lane / MFR) * 8;      // lane group h holds k = 8 h .. 8 h + 7 of a step
+    auto mfma = [&](const bf16x8& a, const bf16x8& b, typename T::AccT& c) {
+        if constexpr (MFR == 32) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+        else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    };
     auto compute = [&](auto bufc) {
-        constexpr int buf = decltype(bufc)::value;
+        constexpr int buf = decltype(bufc)::value * NS;
 #pragma unroll
         for (int ks = 0; ks < CKT / KSTEP; ++ks) {
-            bf16x8 a[T::TM], b[T::TN];
+            bf16x8 a[NS][T::TM], b[NS][T::TN];
 #pragma unroll
-            for (int i = 0; i < T::TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&As[buf][wm0 + i * MFR + frow][ks * KSTEP + fk]);
+            for (int q = 0; q < NS; ++q) {
 #pragma unroll
-            for (int j = 0; j < T::TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][wn0 + j * MFR + frow][ks * KSTEP + fk]);
+                for (int i = 0; i < T::TM; ++i) a[q][i] = *reinterpret_cast<const bf16x8*>(&As[buf + q][wm0 + i * MFR + frow][ks * KSTEP + fk]);
+#pragma unroll
+                for (int j = 0; j < T::TN; ++j) b[q][j] = *reinterpret_cast<const bf16x8*>(&Bs[buf + q][wn0 + j * MFR + frow][ks * KSTEP + fk]);
+            }
 #pragma unroll
             for (int i = 0; i < T::TM; ++i)
 #pragma unroll
                 for (int j = 0; j < T::TN; ++j) {
-                    if constexpr (MFR == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    if constexpr (NS == 1) {
+                        mfma(a[0][i], b[0][j], acc[i][j]);
+                    } else {      // (three independent accumulation chains)
+                        mfma(a[2][i], b[0][j], low[i][j]);
+                        mfma(a[1][i], b[0][j], mid[i][j]);
+                        mfma(a[0][i], b[0][j], acc[i][j]);
+                        mfma(a[0][i], b[2][j], low[i][j]);
+                        mfma(a[0][i], b[1][j], mid[i][j]);
+                        mfma(a[1][i], b[1][j], low[i][j]);
+                    }
                 }
         }
     };
@@ -267,31 +310,251 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p, const u1
     // "write early": at the top of step t buffer t & 1 holds tile t and the registers hold the in-flight loads of tile t + 1; the step
     // writes them to the other buffer, issues tile t + 2 into the same registers, multiplies tile t, one barrier.  The MFMA phase is
     // short here (32..64 cycles per 32x32x16), so the flight of the loads is covered by the other workgroups of the CU.
-    f32x4 ra[T::AROWS], rb[T::BVECS];
-    if (T_total > 0) {
-        issue(ra, rb);
-        store(ra, rb, B0{});
-        if (T_total > 1) issue(ra, rb);
+    f32x4 ra[T::AROWS], rb[NS][T::BVECS];
+    f32x4 ra2[NS == 1 ? 1 : T::AROWS], rb2[NS][NS == 1 ? 1 : T::BVECS];      // the split form's second register stage
+    f32x4 ex[3][EXR], ex2[3][NS == 1 ? 1 : EXR];
+    if constexpr (NS == 1) {
+        if (T_total > 0) {
+            issue(ra, rb, ex);
+            store(ra, rb, ex, B0{});
+            if (T_total > 1) issue(ra, rb, ex);
+        }
+    } else {
+        // tiles t + 1 and t + 2 are in flight while tile t is multiplied (a K-tile's six MFMAs per step are over in a few hundred cycles: one
+        // tile of look-ahead does not cover a load's round trip)
+        if (T_total > 0) {
+            issue(ra, rb, ex);
+            if (T_total > 1) issue(ra2, rb2, ex2);
+            store(ra, rb, ex, B0{});
+            if (T_total > 2) issue(ra, rb, ex);
+        }
     }
     __syncthreads();
-    int t = 0;
-    for (; t + 1 < T_total; t += 2) {
-        store(ra, rb, B1{});
-        if (t + 2 < T_total) issue(ra, rb);
-        compute(B0{});
-        __syncthreads();
-        if (t + 2 < T_total) {
-            store(ra, rb, B0{});
-            if (t + 3 < T_total) issue(ra, rb);
+    if constexpr (NS == 1) {
+        int t = 0;
+        for (; t + 1 < T_total; t += 2) {
+            store(ra, rb, ex, B1{});
+            if (t + 2 < T_total) issue(ra, rb, ex);
+            compute(B0{});
+            __syncthreads();
+            if (t + 2 < T_total) {
+                store(ra, rb, ex, B0{});
+                if (t + 3 < T_total) issue(ra, rb, ex);
+            }
+            compute(B1{});
+            __syncthreads();
         }
-        compute(B1{});
-        __syncthreads();
-    }
-    if (t < T_total) {
-        compute(B0{});
-        __syncthreads();
+        if (t < T_total) {
+            compute(B0{});
+            __syncthreads();
+        }
+    } else {
+        // one panel: multiply tile t, barrier, write tile t + 1 from its register stage, issue tile t + 3 into that stage, barrier
+        for (int t = 0; t < T_total; t += 2) {
+            compute(B0{});
+            __syncthreads();
+            if (t + 1 < T_total) {
+                store(ra2, rb2, ex2, B0{});
+                if (t + 3 < T_total) issue(ra2, rb2, ex2);
+                __syncthreads();
+                compute(B0{});
+                __syncthreads();
+                if (t + 2 < T_total) {
+                    store(ra, rb, ex, B0{});
+                    if (t + 4 < T_total) issue(ra, rb, ex);
+                    __syncthreads();
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j) acc[i][j] += mid[i][j] + low[i][j];
     }
     igemm_epilogue<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
+}
+
+// ------------------------------------------------------------------------------------------------ 3x3 stride-1 zero-padded conv, patch in LDS
+// The implicit-GEMM kernels above fetch (and round or split) every source pixel once per filter tap.  For the 3x3 stride-1 zero-padded
+// convolutions of the ResNet trunk (and their data gradients: the same contraction with mirrored taps) a workgroup instead owns a TH x TW
+// block of output pixels (TH TW <= 64 rows of the GEMM) and keeps the (TH + 2) x (TW + 2) source patch of one 32-channel chunk in LDS, as
+// bf16 (NS = 1) or as the three planes of the split fp32 form (NS = 3): a source pixel is fetched and converted ONCE per chunk (1.56x halo
+// at 8 x 8 instead of 9x), the nine taps are nine shifted views of the patch -- a tap is a constant added to each lane's patch row --, and
+// only the filter tile of the tap (64 outputs x 32 channels per plane, L2-resident) is streamed.  The next chunk's patch is in flight
+// during the nine taps of the current one, the next tap's filter tile during the current tap's MFMAs.
+struct PatchGeo {
+    int TH, TW, tiles_y, tiles_x;
+};
+
+constexpr int PATCH_PIX = 104;      // (TH + 2) (TW + 2) <= 104: 8 x 8 -> 100, 6 x 10 -> 96, 4 x 16 -> 108 is not allowed
+
+template <int NS>
+__global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(IgemmParams p, const u16* __restrict__ w16, PatchGeo geo) {
+    using T = BT64x64k32;
+    constexpr int BM = 64, BN = 64, CKT = 32, LDH = T::LDH;
+    __shared__ __attribute__((aligned(16))) u16 Ap[NS][PATCH_PIX][LDH];
+    __shared__ __attribute__((aligned(16))) u16 Bs[NS][BN][LDH];
+    __shared__ int s_out[BM];
+    float (*const s_stat)[2][BN] = reinterpret_cast<float (*)[2][BN]>(&Bs[0][0][0]);
+    static_assert(sizeof(u16) * BN * LDH >= sizeof(float) * T::WAVES_M * 2 * BN, "statistics scratch fits a filter plane");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = lid % p.ntiles, mt = lid / p.ntiles;
+    const int n0 = nt * BN;
+    const GatherSrc& g = p.g;
+    const int TH = geo.TH, TW = geo.TW, PW = TW + 2, PH = TH + 2;
+    const int per_img = geo.tiles_y * geo.tiles_x;
+    const int img = mt / per_img, tr = mt - img * per_img;
+    const int ty0 = (tr / geo.tiles_x) * TH, tx0 = (tr % geo.tiles_x) * TW;
+
+    if (tid < BM) {
+        const int py = tid / TW, px = tid - py * TW;
+        const int y = ty0 + py, x = tx0 + px;
+        s_out[tid] = (py < TH && y < p.Hd && x < p.Wd) ? (img * p.Hd + y) * p.Wd + x : -1;
+    }
+    // patch staging: thread -> (patch pixel pp0 + 32 j, 4 channels c4); a pixel outside the image reads as zero (the padding)
+    const int c4 = tid & 7, pp0 = tid >> 3;
+    unsigned aoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pp = pp0 + 32 * j;
+        const int ppy = pp / PW, ppx = pp - ppy * PW;
+        const int y = ty0 - 1 + ppy, x = tx0 - 1 + ppx;
+        const bool ok = pp < PH * PW && (unsigned)y < (unsigned)g.Hs && (unsigned)x < (unsigned)g.Ws;
+        aoff[j] = ok ? (unsigned)((((img * g.Hs + y) * g.Ws + x) * g.C1 + c4 * 4) * 4) : OOB;
+    }
+    const unsigned bytes1 = (unsigned)((size_t)g.B * g.Hs * g.Ws * g.C1 * 4);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1, bytes1);
+    const unsigned plane_bytes = (unsigned)((size_t)p.Np_all * p.Kstride * 2);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(w16, (unsigned)((size_t)(p.n_begin + p.n_count) * p.Kstride * 2) + (NS - 1) * plane_bytes);
+    const int bn = tid >> 2, bcb = tid & 3;                       // filter tile: row (output) and 16-byte piece (8 channels)
+    const unsigned boff = (n0 + bn < p.n_count) ? (unsigned)(((p.n_begin + n0 + bn) * p.Kstride + bcb * 8) * 2) : OOB;
+
+    const int nchunks = p.Kp / CKT;
+    auto issueA = [&](f32x4 (&ra)[4], int chunk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[j] = buf_load4s(rs1, aoff[j], chunk * CKT * 4);
+    };
+    auto storeA = [&](const f32x4 (&ra)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pp = pp0 + 32 * j;
+            if (pp < PATCH_PIX) {
+                if constexpr (NS == 1) {
+                    *reinterpret_cast<u32x2*>(&Ap[0][pp][c4 * 4]) = pack_bf16x4(ra[j]);
+                } else {
+                    const bf16x4 h = __builtin_convertvector(ra[j], bf16x4);
+                    const f32x4 r1 = ra[j] - __builtin_convertvector(h, f32x4);            // exact
+                    const bf16x4 m = __builtin_convertvector(r1, bf16x4);
+                    const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);               // exact
+                    *reinterpret_cast<u32x2*>(&Ap[0][pp][c4 * 4]) = __builtin_bit_cast(u32x2, h);
+                    *reinterpret_cast<u32x2*>(&Ap[1][pp][c4 * 4]) = __builtin_bit_cast(u32x2, m);
+                    *reinterpret_cast<u32x2*>(&Ap[2][pp][c4 * 4]) = pack_bf16x4(r2);
+                }
+            }
+        }
+    };
+    auto issueB = [&](f32x4 (&rb)[NS], int chunk, int tap) {
+        const int kb = (tap * p.Kp + chunk * CKT) * 2;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) rb[q] = buf_load4s(rsw, boff, kb + q * (int)plane_bytes);
+    };
+    auto storeB = [&](const f32x4 (&rb)[NS]) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) *reinterpret_cast<f32x4*>(&Bs[q][bn][bcb * 8]) = rb[q];
+    };
+
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    typename T::AccT acc[1][1], mid, low;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; mid[r] = 0.f; low[r] = 0.f; }
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    // this lane's A row = output pixel (py, px) of the block -> patch pixel (py + dy, px + dx), dy / dx = the tap (mirrored for the data gradient)
+    int prow;
+    {
+        const int r = wm0 + frow;
+        const int py = r / TW, px = r - py * TW;
+        prow = py < TH ? py * PW + px : 0;                       // rows past the block multiply pixel 0 (their results are dropped)
+    }
+    const u16* const a_lane = &Ap[0][prow][fk];
+    const u16* const b_lane = &Bs[0][wn0 + frow][fk];
+    constexpr int APL = PATCH_PIX * LDH, BPL = BN * LDH;         // plane strides in elements
+    auto compute = [&](int tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int shift = __builtin_amdgcn_readfirstlane((g.sign > 0 ? ky * PW + kx : (2 - ky) * PW + (2 - kx)) * LDH);
+#pragma unroll
+        for (int ks = 0; ks < CKT / 16; ++ks) {
+            bf16x8 a[NS], b[NS];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                a[q] = *reinterpret_cast<const bf16x8*>(a_lane + q * APL + shift + ks * 16);
+                b[q] = *reinterpret_cast<const bf16x8*>(b_lane + q * BPL + ks * 16);
+            }
+            if constexpr (NS == 1) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[0][0], 0, 0, 0);
+            } else {
+                low = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], low, 0, 0, 0);
+                mid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], mid, 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[0][0], 0, 0, 0);
+                low = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], low, 0, 0, 0);
+                mid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], mid, 0, 0, 0);
+                low = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], low, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x4 ra[4], rb[NS];
+    issueA(ra, 0);
+    issueB(rb, 0, 0);
+    storeA(ra);
+    storeB(rb);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        if (more) issueA(ra, chunk + 1);                          // lands during the nine taps below
+        for (int tap = 0; tap < 9; ++tap) {
+            const bool nextB = tap < 8 || more;
+            if (nextB) issueB(rb, tap < 8 ? chunk : chunk + 1, tap < 8 ? tap + 1 : 0);
+            compute(tap);
+            __syncthreads();
+            if (tap == 8 && more) storeA(ra);
+            if (nextB) {
+                storeB(rb);
+                __syncthreads();
+            }
+        }
+    }
+    if constexpr (NS > 1) acc[0][0] += mid + low;
+    igemm_epilogue<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
+}
+
+// The block shape for an H x W map: TH TW <= 64 rows, (TH + 2)(TW + 2) <= PATCH_PIX, fewest wasted rows, then the smallest halo.
+static void patch_block(int H, int W, int& TH, int& TW) {
+    double best = 1e30;
+    TH = 8; TW = 8;
+    for (int th = 1; th <= 8; ++th)
+        for (int tw = 4; tw <= 64; ++tw) {
+            if (th * tw > 64 || (th + 2) * (tw + 2) > PATCH_PIX) continue;
+            const double tiles = (double)((H + th - 1) / th) * ((W + tw - 1) / tw);
+            const double cost = tiles * 64.0 * (1.0 + 0.05 * (double)((th + 2) * (tw + 2)) / (th * tw)) * ((tw & 7) ? 1.02 : 1.0);
+            if (cost < best) { best = cost; TH = th; TW = tw; }
+        }
+}
+
+// 1 = the descriptor runs on conv3x3_patch_kernel (fills geo): a 3x3 stride-1 zero-padded convolution or its data gradient, one source
+static bool patch_plan(const mcav_igemm_desc* d, PatchGeo& geo) {
+    static const int enabled = [] { const char* e = getenv("MCAV_PATCH"); return e ? atoi(e) : 1; }();
+    if (!enabled || !d || !d->w16 || (d->mma != 1 && d->mma != 2)) return false;
+    if (d->mode != MCAV_G_DIRECT || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_mode != MCAV_PAD_ZERO) return false;
+    if (!((d->sign == 1 && d->offset == -1) || (d->sign == -1 && d->offset == 1))) return false;
+    if (d->C2 != 0 || d->up1 || d->pool || d->w_upmerge) return false;
+    if (d->C1 % 32 != 0 || d->Kp != d->C1 || d->Hd != d->Hs || d->Wd != d->Ws || d->n_count < 32) return false;
+    if (d->groups > 1 && d->B % d->groups != 0) return false;
+    patch_block(d->Hd, d->Wd, geo.TH, geo.TW);
+    geo.tiles_y = (d->Hd + geo.TH - 1) / geo.TH;
+    geo.tiles_x = (d->Wd + geo.TW - 1) / geo.TW;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -303,12 +566,15 @@ constexpr int KPB = 64;
 
 __device__ __forceinline__ int wsw(int row, int kb) { return ((kb ^ ((row >> 1) & 7)) << 3); }      // element offset of k-block kb in a panel row
 
-template <int DUMMY>
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradParams p) {
+// NS = 3: the fp32 contraction on split operands (see igemm_bf16_kernel): both operands are split on their way into LDS, one panel of
+// three planes each, half the offset-table capacity (52 KB of LDS: three workgroups per CU).
+template <int NS>
+__global__ __launch_bounds__(256, NS == 3 ? 3 : 2) void wgrad_bf16_kernel(WgradParams p) {
     constexpr int BM = 64, BN = 64;
-    __shared__ __attribute__((aligned(16))) u16 Xs[2][BM][KPB];      // [kflat row][64 pixels], 128-byte rows, 16-byte slots XOR-swizzled
-    __shared__ __attribute__((aligned(16))) u16 Ys[2][BN][KPB];
-    __shared__ unsigned s_tab[WG_TABCAP];
+    constexpr int NB = NS == 1 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) u16 Xs[NB * NS][BM][KPB];      // [kflat row][64 pixels], 128-byte rows, 16-byte slots XOR-swizzled
+    __shared__ __attribute__((aligned(16))) u16 Ys[NB * NS][BN][KPB];
+    __shared__ unsigned s_tab[NS == 1 ? WG_TABCAP : WG_TABCAP / 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per_split = p.mtiles * p.ntiles;
     // all row / column tiles of one pixel split read the same pixels (each tap a shifted view of x, every tile the same dy): consecutive
@@ -424,32 +690,66 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) bsum += rv[j];
         }
-        u16 (*dst)[KPB] = waveA ? Xs[buf] : Ys[buf];
+        u16 (*dst)[BM][KPB] = waveA ? &Xs[buf * NS] : &Ys[buf * NS];
+        static_assert(BM == BN, "one panel shape");
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            bf16x8 h;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) h[j] = (__bf16)rv[j][c];
             const int row = col * 4 + c;
-            *reinterpret_cast<bf16x8*>(&dst[row][wsw(row, pg)]) = h;
+            bf16x8 h;
+            if constexpr (NS == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) h[j] = (__bf16)rv[j][c];
+                *reinterpret_cast<bf16x8*>(&dst[0][row][wsw(row, pg)]) = h;
+            } else {
+                bf16x8 m, l;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = rv[j][c];
+                    h[j] = (__bf16)v;
+                    const float r1 = v - (float)h[j];                       // exact
+                    m[j] = (__bf16)r1;
+                    l[j] = (__bf16)(r1 - (float)m[j]);
+                }
+                *reinterpret_cast<bf16x8*>(&dst[0][row][wsw(row, pg)]) = h;
+                *reinterpret_cast<bf16x8*>(&dst[1][row][wsw(row, pg)]) = m;
+                *reinterpret_cast<bf16x8*>(&dst[2][row][wsw(row, pg)]) = l;
+            }
         }
     };
 
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-    f32x16 acc;
+    f32x16 acc, mid, low;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = mid[r] = low[r] = 0.f;
     const int fr = lane & 31, fh = lane >> 5;
     auto compute = [&](auto bufc) {
-        constexpr int buf = decltype(bufc)::value;
-        bf16x8 a[KPB / 16], b[KPB / 16];
+        constexpr int buf = decltype(bufc)::value * NS;
+        if constexpr (NS == 1) {
+            bf16x8 a[KPB / 16], b[KPB / 16];
 #pragma unroll
-        for (int ks = 0; ks < KPB / 16; ++ks) {
-            a[ks] = *reinterpret_cast<const bf16x8*>(&Xs[buf][wm0 + fr][wsw(wm0 + fr, 2 * ks + fh)]);
-            b[ks] = *reinterpret_cast<const bf16x8*>(&Ys[buf][wn0 + fr][wsw(wn0 + fr, 2 * ks + fh)]);
+            for (int ks = 0; ks < KPB / 16; ++ks) {
+                a[ks] = *reinterpret_cast<const bf16x8*>(&Xs[buf][wm0 + fr][wsw(wm0 + fr, 2 * ks + fh)]);
+                b[ks] = *reinterpret_cast<const bf16x8*>(&Ys[buf][wn0 + fr][wsw(wn0 + fr, 2 * ks + fh)]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KPB / 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b[ks], acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KPB / 16; ++ks) {
+                bf16x8 a[3], b[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    a[q] = *reinterpret_cast<const bf16x8*>(&Xs[buf + q][wm0 + fr][wsw(wm0 + fr, 2 * ks + fh)]);
+                    b[q] = *reinterpret_cast<const bf16x8*>(&Ys[buf + q][wn0 + fr][wsw(wn0 + fr, 2 * ks + fh)]);
+                }
+                low = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], low, 0, 0, 0);
+                mid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], mid, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+                low = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], low, 0, 0, 0);
+                mid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], mid, 0, 0, 0);
+                low = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], low, 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int ks = 0; ks < KPB / 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b[ks], acc, 0, 0, 0);
     };
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
@@ -457,31 +757,63 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradParams p) {
         if (((tt + 1) & ((1 << cht) - 1)) == 0 && ((tt + 1) >> cht) + 1 < nchunks) build_chunk(((tt + 1) >> cht) + 1);
     };
 
-    f32x4 rv[8];
-    if (T_total > 0) {
-        issue(rv);
-        store(rv, B0{});
-        if (T_total > 1) issue(rv);
+    f32x4 rv[8], rv2[NS == 1 ? 1 : 8];
+    if constexpr (NS == 1) {
+        if (T_total > 0) {
+            issue(rv);
+            store(rv, B0{});
+            if (T_total > 1) issue(rv);
+        }
+    } else {
+        if (T_total > 0) {
+            issue(rv);
+            if (T_total > 1) issue(rv2);
+            store(rv, B0{});
+            if (T_total > 2) issue(rv);
+        }
     }
     __syncthreads();
-    int t = 0;
-    for (; t + 1 < T_total; t += 2) {
-        maybe_build(t);
-        store(rv, B1{});
-        if (t + 2 < T_total) issue(rv);
-        compute(B0{});
-        __syncthreads();
-        maybe_build(t + 1);
-        if (t + 2 < T_total) {
-            store(rv, B0{});
-            if (t + 3 < T_total) issue(rv);
+    if constexpr (NS == 1) {
+        int t = 0;
+        for (; t + 1 < T_total; t += 2) {
+            maybe_build(t);
+            store(rv, B1{});
+            if (t + 2 < T_total) issue(rv);
+            compute(B0{});
+            __syncthreads();
+            maybe_build(t + 1);
+            if (t + 2 < T_total) {
+                store(rv, B0{});
+                if (t + 3 < T_total) issue(rv);
+            }
+            compute(B1{});
+            __syncthreads();
         }
-        compute(B1{});
-        __syncthreads();
-    }
-    if (t < T_total) {
-        compute(B0{});
-        __syncthreads();
+        if (t < T_total) {
+            compute(B0{});
+            __syncthreads();
+        }
+    } else {
+        // two register stages: tiles t + 1 and t + 2 in flight while tile t is multiplied (see igemm_bf16_kernel)
+        for (int t = 0; t < T_total; t += 2) {
+            maybe_build(t);
+            compute(B0{});
+            __syncthreads();
+            if (t + 1 < T_total) {
+                store(rv2, B0{});
+                if (t + 3 < T_total) issue(rv2);
+                __syncthreads();
+                maybe_build(t + 1);
+                compute(B0{});
+                __syncthreads();
+                if (t + 2 < T_total) {
+                    store(rv, B0{});
+                    if (t + 4 < T_total) issue(rv);
+                    __syncthreads();
+                }
+            }
+        }
+        acc += mid + low;
     }
 
     float* slab = p.slab + (size_t)split * (p.Ktot + 1) * p.slabN;
@@ -507,17 +839,17 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-template <class T>
+template <class T, int NS = 1>
 inline void launch_igemm_bf16(const IgemmParams& p, const void* w16, bool refl, hipStream_t s) {
     const int grid = p.mtiles * p.ntiles;
     const size_t tab_bytes = sizeof(unsigned) * (size_t)p.taps * T::BM * (p.g.C2 > 0 ? 2 : 1);
-    if (refl) timed_launch(igemm_bf16_kernel<T, 1>, grid, dim3(256), tab_bytes, s, p, reinterpret_cast<const u16*>(w16));
-    else timed_launch(igemm_bf16_kernel<T, 0>, grid, dim3(256), tab_bytes, s, p, reinterpret_cast<const u16*>(w16));
+    if (refl) timed_launch(igemm_bf16_kernel<T, 1, NS>, grid, dim3(256), tab_bytes, s, p, reinterpret_cast<const u16*>(w16));
+    else timed_launch(igemm_bf16_kernel<T, 0, NS>, grid, dim3(256), tab_bytes, s, p, reinterpret_cast<const u16*>(w16));
 }
 
 // Which bf16 tile (0 = the launch is not one the bf16 kernels cover: the caller runs the fp32 path).  Sets *refl.
 static int bf16_tile_for(const mcav_igemm_desc* d, bool* refl) {
-    if (!d || !d->w16 || d->mma != 1) return 0;
+    if (!d || !d->w16 || (d->mma != 1 && d->mma != 2)) return 0;
     if (d->pool || d->w_upmerge) return 0;                            // pooled / merged-tap forms stay on the fp32 kernels
     if (d->kh * d->kw > TAB_TAPS || d->Kp % 32 != 0 || d->C1 + d->C2 != d->Kp) return 0;
     if ((d->C1 & 3) || (d->C2 & 3) || (d->C2 > 0 && d->C1 % 32 != 0)) return 0;
@@ -527,12 +859,16 @@ static int bf16_tile_for(const mcav_igemm_desc* d, bool* refl) {
     const bool radj = d->mode == MCAV_G_ADJ_REFLECT && d->C2 == 0;
     if (!direct && !radj) return 0;
     *refl = radj;
-    const bool k64 = d->Kp % 64 == 0 && (d->C2 == 0 || d->C1 % 64 == 0);
+    const bool k64 = d->mma == 1 && d->Kp % 64 == 0 && (d->C2 == 0 || d->C1 % 64 == 0);      // (the split form keeps 32-deep K-tiles: three planes per panel)
     const long M = (long)d->B * d->Hd * d->Wd;
     const long wg64 = ((M + 63) / 64) * ((d->n_count + 63) / 64);
     int shape = 10;                                                   // 64 x 64
     if (wg64 >= 4096 && !radj) shape = 8;                             // many rows: 128 x 64 (half the filter re-reads)
     else if (wg64 < 512) shape = 12;                                  // few rows (6x20 maps): 32 x 64
+    if (d->mma == 2) {
+        static const int forced = [] { const char* e = getenv("MCAV_SPLIT_TILE"); return e ? atoi(e) : 0; }();      // tuning knob: 10 / 8 / 12
+        if ((forced == 10 || forced == 12 || (forced == 8 && !radj))) shape = forced;
+    }
     return shape * 2 + (k64 ? 1 : 0);
 }
 
@@ -551,9 +887,30 @@ int mcav_bf16_igemm(const mcav_igemm_desc* d, hipStream_t s) {
     IgemmParams p;
     int tile;
     // (past this point the caller may have put the bf16 copy into d->w as well: never fall through to the fp32 kernels)
+    PatchGeo geo;
+    if (patch_plan(d, geo)) {
+        dd.tile = 10;
+        if (!fill_params(&dd, p, tile) || p.upm) return MCAV_E_INVALID;
+        if ((long)d->Np * p.Kstride * 2 * (d->mma == 2 ? 3 : 1) >= 0x7fffffffL) return MCAV_E_INVALID;
+        p.mtiles = d->B * geo.tiles_y * geo.tiles_x;                  // rows of the statistics slab = blocks, image-major (groups = runs of images)
+        p.ntiles = (p.n_count + 63) / 64;
+        if (d->mma == 2) timed_launch(conv3x3_patch_kernel<3>, p.mtiles * p.ntiles, dim3(256), 0, s, p, reinterpret_cast<const u16*>(d->w16), geo);
+        else timed_launch(conv3x3_patch_kernel<1>, p.mtiles * p.ntiles, dim3(256), 0, s, p, reinterpret_cast<const u16*>(d->w16), geo);
+        return launch_status();
+    }
     if (!fill_params(&dd, p, tile) || p.upm) return MCAV_E_INVALID;
     if ((long)d->Np * p.Kstride * 2 >= 0x7fffffffL) return MCAV_E_INVALID;
     const bool k64 = bt & 1;
+    if (d->mma == 2) {
+        if ((long)d->Np * p.Kstride * 2 * 3 >= 0x7fffffffL) return MCAV_E_INVALID;
+        switch (tile) {
+            case 10: launch_igemm_bf16<BT64x64k32, 3>(p, d->w16, refl, s); break;
+            case 8: launch_igemm_bf16<BT128x64k32, 3>(p, d->w16, refl, s); break;
+            case 12: launch_igemm_bf16<BT32x64k32, 3>(p, d->w16, refl, s); break;
+            default: return MCAV_E_INVALID;
+        }
+        return launch_status();
+    }
     switch (tile) {
         case 10: if (k64) launch_igemm_bf16<BT64x64k64>(p, d->w16, refl, s); else launch_igemm_bf16<BT64x64k32>(p, d->w16, refl, s); break;
         case 8: if (k64) launch_igemm_bf16<BT128x64k64>(p, d->w16, refl, s); else launch_igemm_bf16<BT128x64k32>(p, d->w16, refl, s); break;
@@ -569,6 +926,8 @@ int mcav_bf16_igemm_mtiles(const mcav_igemm_desc* d) {
     bool refl = false;
     const int bt = bf16_tile_for(d, &refl);
     if (!bt) return 0;
+    PatchGeo geo;
+    if (patch_plan(d, geo)) return d->B * geo.tiles_y * geo.tiles_x;
     mcav_igemm_desc dd = *d;
     dd.tile = bt >> 1;
     dd.w_upmerge = nullptr;
@@ -585,7 +944,7 @@ MCAV_EXPORT int mcav_igemm_uses_bf16(const mcav_igemm_desc* d) {
 
 // Plans the bf16 weight-gradient launch into pl (splits over 64-pixel K-tiles, table chunking); false = not eligible.
 bool mcav_bf16_wgrad_plan(const mcav_wgrad_desc* d, WgradPlan& pl) {
-    if (!d || d->mma != 1 || d->upm) return false;
+    if (!d || (d->mma != 1 && d->mma != 2) || d->upm) return false;
     if (d->mode != MCAV_G_DIRECT || d->Kp % 16 != 0 || d->C1 + d->C2 != d->Kp || d->Cin != d->Kp) return false;
     if ((d->C1 & 15) || (d->C2 & 15) || d->Cout < 32 || (d->Cdy & 3) || (d->dy_choff & 3)) return false;
     mcav_wgrad_desc dd = *d;
@@ -621,12 +980,14 @@ bool mcav_bf16_wgrad_plan(const mcav_wgrad_desc* d, WgradPlan& pl) {
     }
     const int epp = ntmax * (d->C2 > 0 ? 2 : 1);
     p.tab_cht_log2 = 20;
-    if ((long)p.pix_per_split * epp > WG_TABCAP) {
-        if (2 * 2 * KPB * epp > WG_TABCAP) return false;              // not even two 2-tile chunks fit
+    const int tabcap = d->mma == 2 ? WG_TABCAP / 2 : WG_TABCAP;       // (the split form gives half of the table's LDS to its planes)
+    if ((long)p.pix_per_split * epp > tabcap) {
+        if (2 * 2 * KPB * epp > tabcap) return false;                 // not even two 2-tile chunks fit
         int lg = 1;
-        while ((2 << lg) * KPB * epp <= WG_TABCAP / 2) ++lg;
+        while ((2 << lg) * KPB * epp <= tabcap / 2) ++lg;
         p.tab_cht_log2 = lg;
     }
+    p.split_planes = d->mma == 2;
     pl.use_tab = true;
     pl.slab_bytes = align_up(sizeof(float) * (size_t)p.splits * (p.Ktot + 1) * p.slabN, 256);
     pl.groups = p.splits > 8 ? 8 : 0;
@@ -642,6 +1003,28 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
 }
 }  // namespace mcav
 
+namespace mcav {
+__global__ __launch_bounds__(256) void f32_to_bf16_planes_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = src[i];
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        dst[i] = h;
+        dst[n + i] = m;
+        dst[2 * n + i] = (__bf16)(r1 - (float)m);
+    }
+}
+}  // namespace mcav
+
+MCAV_EXPORT int mcav_f32_to_bf16_planes(const float* src, void* dst_bf16, size_t n, void* stream) {
+    if (!src || !dst_bf16) return MCAV_E_INVALID;
+    if (n == 0) return MCAV_OK;
+    const size_t b = (n + 255) / 256;
+    f32_to_bf16_planes_kernel<<<(unsigned)(b < 4096 ? b : 4096), 256, 0, as_stream(stream)>>>(src, reinterpret_cast<__bf16*>(dst_bf16), n);
+    return launch_status();
+}
+
 MCAV_EXPORT int mcav_f32_to_bf16(const float* src, void* dst_bf16, size_t n, void* stream) {
     if (!src || !dst_bf16) return MCAV_E_INVALID;
     if (n == 0) return MCAV_OK;
@@ -651,5 +1034,6 @@ MCAV_EXPORT int mcav_f32_to_bf16(const float* src, void* dst_bf16, size_t n, voi
 }
 
 void mcav_bf16_wgrad_launch(const WgradParams& p, hipStream_t s) {
-    timed_launch(wgrad_bf16_kernel<0>, p.splits * p.mtiles * p.ntiles, dim3(256), 0, s, p);
+    if (p.split_planes) timed_launch(wgrad_bf16_kernel<3>, p.splits * p.mtiles * p.ntiles, dim3(256), 0, s, p);
+    else timed_launch(wgrad_bf16_kernel<1>, p.splits * p.mtiles * p.ntiles, dim3(256), 0, s, p);
 }

@@ -1654,9 +1654,21 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem*
         if (items[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     PackItem it = items[lo];
-    const bool to_bf16 = (it.transposed & 2) != 0;      // bit 1: the destination holds bf16 (the filter copies of the bf16 MFMA kernels)
+    const bool to_bf16 = (it.transposed & 6) != 0;      // bit 1: the destination holds bf16 (the filter copies of the bf16 MFMA kernels)
+    const bool planes = (it.transposed & 4) != 0;       // bit 2: ... as three planes h, m, l of Np x Kstride elements each (the fp32 contraction on split operands)
     it.transposed &= 1;
     __bf16* const dst16 = reinterpret_cast<__bf16*>(it.dst);
+    const size_t plane = (size_t)it.Np * it.Kstride;
+    auto put16 = [&](size_t o, float v) {
+        const __bf16 h = (__bf16)v;
+        dst16[o] = h;
+        if (planes) {
+            const float r1 = v - (float)h;
+            const __bf16 m = (__bf16)r1;
+            dst16[plane + o] = m;
+            dst16[2 * plane + o] = (__bf16)(r1 - (float)m);
+        }
+    };
     const int bl = blockIdx.x - it.first_block, tid = threadIdx.x;
     if (!it.transposed) {
         const int n = bl, run = it.Cin * it.taps;
@@ -1671,7 +1683,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem*
             const int tap = kf / it.Kp, k = kf - tap * it.Kp;
             float v = 0.f;
             if (n < it.Cout && tap < it.taps && k < it.Cin) v = staged ? buf[k * it.taps + tap] : it.src[((size_t)n * it.Cin + k) * it.taps + tap];
-            if (to_bf16) dst16[(size_t)n * it.Kstride + kf] = (__bf16)v;
+            if (to_bf16) put16((size_t)n * it.Kstride + kf, v);
             else drow[kf] = v;
         }
         return;
@@ -1691,7 +1703,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem*
         const int r = q / it.taps, tap = q - r * it.taps;
         if (ci0 + r < it.Np && co0 + co < it.Kp) {
             const size_t o = (size_t)(ci0 + r) * it.Kstride + tap * it.Kp + co0 + co;
-            if (to_bf16) dst16[o] = (__bf16)buf[co * ld + q];
+            if (to_bf16) put16(o, buf[co * ld + q]);
             else it.dst[o] = buf[co * ld + q];
         }
     }
@@ -1903,7 +1915,7 @@ MCAV_EXPORT int mcav_igemm_mtiles(const mcav_igemm_desc* d) {
     int tile;
     if (!fill_params(d, p, tile)) return MCAV_E_INVALID;
     if (const int st = mcav_stem_mtiles(d)) return st;             // the stem kernel's 8 x 32 output tiles
-    if (d->mma == 1) {                                             // the bf16 kernels choose their own tile shape
+    if (d->mma == 1 || d->mma == 2) {                              // the bf16 kernels choose their own tile shape
         const int mt = mcav_bf16_igemm_mtiles(d);
         if (mt > 0) return mt;
     }
@@ -1924,7 +1936,7 @@ MCAV_EXPORT int mcav_igemm(const mcav_igemm_desc* d, void* stream) {
     hipStream_t s = as_stream(stream);
     if (mcav_try_halo(d, s)) return launch_status();
     if (mcav_try_stem(d, p, s)) return launch_status();
-    if (d->mma == 1) {                                   // bf16 MFMA tiles (conv_bf16.hip) where the launch qualifies, else the fp32 kernels below
+    if (d->mma == 1 || d->mma == 2) {                    // bf16 MFMA tiles (conv_bf16.hip) where the launch qualifies, else the fp32 kernels below
         const int rc = mcav_bf16_igemm(d, s);
         if (rc != 1) return rc;
     }
@@ -2093,18 +2105,18 @@ inline void launch_wgrad(const WgradParams& p, bool use_tab, hipStream_t s) {
 
 MCAV_EXPORT size_t mcav_wgrad_workspace_bytes(const mcav_wgrad_desc* d) {
     WgradPlan pl;
-    if (!(d && d->mma == 1 && mcav_bf16_wgrad_plan(d, pl)) && !plan_wgrad(d, pl)) return 0;
+    if (!(d && d->mma != 0 && mcav_bf16_wgrad_plan(d, pl)) && !plan_wgrad(d, pl)) return 0;
     return pl.slab_bytes + pl.pre_bytes;
 }
 
 MCAV_EXPORT int mcav_wgrad_uses_bf16(const mcav_wgrad_desc* d) {
     WgradPlan pl;
-    return d && d->mma == 1 && mcav_bf16_wgrad_plan(d, pl);
+    return d && d->mma != 0 && mcav_bf16_wgrad_plan(d, pl);
 }
 
 // the GEMM part of a weight gradient: partial tiles into the slab at `workspace`
 static int wgrad_gemm(const mcav_wgrad_desc* d, void* workspace, size_t workspace_bytes, hipStream_t s, WgradPlan& pl) {
-    const bool bf16 = d && d->mma == 1 && mcav_bf16_wgrad_plan(d, pl);      // bf16 MFMA tiles where the launch qualifies (conv_bf16.hip)
+    const bool bf16 = d && d->mma != 0 && mcav_bf16_wgrad_plan(d, pl);      // bf16 MFMA tiles where the launch qualifies (conv_bf16.hip)
     if ((!bf16 && !plan_wgrad(d, pl)) || !workspace) return MCAV_E_INVALID;
     if (workspace_bytes < pl.slab_bytes + pl.pre_bytes) return MCAV_E_WORKSPACE;
     const int cin_total = d->Cin_total > 0 ? d->Cin_total : d->Cin;

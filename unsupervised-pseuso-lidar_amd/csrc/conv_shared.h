@@ -346,6 +346,7 @@ struct WgradParams {
     int tab_cht_log2;              // wgrad_tab_kernel: log2 of the tiles per table chunk (>= 20: the whole split is one chunk)
     int upm;                       // merged-tap upsample (mcav_wgrad_desc.upm): rows = 16 (class, merged tap) x Kp, pixels = LOW-resolution ones
     int Hf, Wf;                    // upm: full-resolution size of dy (Hd, Wd hold the low-resolution one)
+    int split_planes;              // conv_bf16.hip: 1 = the fp32 contraction on three bf16 planes per operand (mcav_wgrad_desc.mma = 2)
 };
 
 constexpr int KP = 32;   // pixels per K-tile of the wgrad GEMM

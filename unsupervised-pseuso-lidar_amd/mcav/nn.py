@@ -55,6 +55,7 @@ L.register({
     "mcav_igemm_uses_bf16": (c_i, [ctypes.POINTER(IgemmDesc)]),
     "mcav_wgrad_uses_bf16": (c_i, [ctypes.POINTER(WgradDesc)]),
     "mcav_f32_to_bf16": (c_i, [c_p, c_p, c_sz, c_p]),
+    "mcav_f32_to_bf16_planes": (c_i, [c_p, c_p, c_sz, c_p]),
     "mcav_pack_stem_weights": (c_i, [c_p, c_i, c_i, c_p, c_p]),
     "mcav_wgrad_workspace_bytes": (c_sz, [ctypes.POINTER(WgradDesc)]),
     "mcav_wgrad": (c_i, [ctypes.POINTER(WgradDesc), c_p, c_sz, c_p]),
@@ -155,8 +156,9 @@ class _PackItem(ctypes.Structure):
                 ("Kstride", c_i), ("first_block", c_i)]
 
 
-MMA_FP32, MMA_BF16 = 0, 1
-_KINDS = {"f": (False, False), "b": (True, False), "f16": (False, True), "b16": (True, True)}      # kind -> (transposed, bf16)
+MMA_FP32, MMA_BF16, MMA_SPLIT = 0, 1, 2
+# kind -> (transposed, bf16 planes: 0 = an fp32 copy, 1 = bf16, 3 = the planes h, m, l of the fp32 contraction on split operands)
+_KINDS = {"f": (False, 0), "b": (True, 0), "f16": (False, 1), "b16": (True, 1), "f16s": (False, 3), "b16s": (True, 3)}
 
 
 class PackRegistry:
@@ -182,8 +184,8 @@ class PackRegistry:
             buf = spec._packs[kind]
             np_, kp_ = (up16(spec.cin), up16(spec.cout)) if tr else (spec.np, spec.kp)
             it.src, it.dst = spec.weight.data_ptr(), buf.data_ptr()
-            it.Cout, it.Cin, it.taps, it.transposed = spec.cout, spec.cin, spec.kh * spec.kw, int(tr) | (2 if h else 0)
-            it.Np, it.Kp, it.Kstride, it.first_block = np_, kp_, buf.shape[1], blk
+            it.Cout, it.Cin, it.taps, it.transposed = spec.cout, spec.cin, spec.kh * spec.kw, int(tr) | (4 if h == 3 else 2 if h else 0)
+            it.Np, it.Kp, it.Kstride, it.first_block = np_, kp_, buf.shape[1], blk      # (buf.shape[0] = Np rows per plane x planes)
             blk += L.lib().mcav_pack_weights_blocks(it.taps, int(tr), np_, kp_)
         raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
         self.table = raw.to(device)
@@ -245,12 +247,14 @@ class ConvSpec:
             if buf is None or buf.device != self.weight.device:
                 # first use: derive this one copy (a full repack per new copy would cost ~80 whole-registry launches in the first step)
                 shape = (up16(self.cin), taps * up16(self.cout)) if tr else (self.np, up16(taps * self.kp))
-                buf = torch.empty(shape, dtype=torch.bfloat16 if h else torch.float32, device=self.weight.device)
+                buf = torch.empty((shape[0] * max(h, 1), shape[1]), dtype=torch.bfloat16 if h else torch.float32, device=self.weight.device)
                 f32 = torch.empty(shape, dtype=torch.float32, device=self.weight.device) if h else buf
                 np_, kp_ = (up16(self.cin), up16(self.cout)) if tr else (self.np, self.kp)
                 L.check(L.lib().mcav_pack_weights(P(self.weight), self.cout, self.cin, self.kh, self.kw, int(tr), P(f32), np_, kp_, L.stream()),
                         "mcav_pack_weights")
-                if h:
+                if h == 3:
+                    L.check(L.lib().mcav_f32_to_bf16_planes(P(f32), P(buf), f32.numel(), L.stream()), "mcav_f32_to_bf16_planes")
+                elif h:
                     L.check(L.lib().mcav_f32_to_bf16(P(f32), P(buf), f32.numel(), L.stream()), "mcav_f32_to_bf16")
                 self._packs[kind] = buf
                 self._keys[kind] = key
@@ -271,6 +275,13 @@ class ConvSpec:
 
     def packed_bwd16(self):
         return self._packed("b16")
+
+    def packed_fwd16s(self):
+        """[3][Np][Kstride] bf16: the planes h, m, l of the forward filter (MMA_SPLIT)."""
+        return self._packed("f16s")
+
+    def packed_bwd16s(self):
+        return self._packed("b16s")
 
     def is_stem(self):
         """The two 7x7 stride-2 stems the patch-in-LDS kernels of csrc/conv_stem.hip cover: the depth net's image stem and PoseNet conv1."""
@@ -314,24 +325,34 @@ class ConvSpec:
             self._key_ua16 = None
         if not bf16:
             return self._upa
-        if getattr(self, "_upa16", None) is None or self._key_ua16 != key:
-            if getattr(self, "_upa16", None) is None:
-                self._upa16 = torch.empty(self._upa.shape, dtype=torch.bfloat16, device=self._upa.device)
-            L.check(L.lib().mcav_f32_to_bf16(P(self._upa), P(self._upa16), self._upa.numel(), L.stream()), "mcav_f32_to_bf16")
+        planes = 3 if bf16 == 3 else 1                      # bf16 = 3: the planes h, m, l (MMA_SPLIT)
+        if getattr(self, "_upa16", None) is None or self._key_ua16 != key or self._upa16.shape[0] != planes * self._upa.shape[0]:
+            if getattr(self, "_upa16", None) is None or self._upa16.shape[0] != planes * self._upa.shape[0]:
+                self._upa16 = torch.empty((planes * self._upa.shape[0], self._upa.shape[1]), dtype=torch.bfloat16, device=self._upa.device)
+            if planes == 3:
+                L.check(L.lib().mcav_f32_to_bf16_planes(P(self._upa), P(self._upa16), self._upa.numel(), L.stream()), "mcav_f32_to_bf16_planes")
+            else:
+                L.check(L.lib().mcav_f32_to_bf16(P(self._upa), P(self._upa16), self._upa.numel(), L.stream()), "mcav_f32_to_bf16")
             self._key_ua16 = key
         return self._upa16
+
+
+SPLIT_NAMES = ("fp32-split", "fp32_split", "f32s", "fp32s")
 
 
 def set_compute_dtype(module, dtype):
     """Opt-in bf16 MFMA conv tiles for every convolution of `module` (BASELINE.json configs[2] / [4]): torch.bfloat16 / "bf16" switches the
     launches the bf16 kernels cover (csrc/conv_bf16.hip) to bf16 operands with fp32 accumulation; torch.float32 / "fp32" switches back.
-    Master weights, activations in HBM, BatchNorm statistics and gradients stay fp32."""
+    Master weights, activations in HBM, BatchNorm statistics and gradients stay fp32.
+    "fp32-split": the same launches as fp32 contractions carried by the bf16 MFMA -- every operand element split into three bf16 planes, six
+    plane products accumulated in fp32 (mcav_igemm_desc.mma = 2): fp32 results (at least as exact as the fp32 MFMA's) at 6 / 16 of its MFMA time."""
     bf16 = dtype in (torch.bfloat16, "bf16", "bfloat16")
-    if not bf16 and dtype not in (torch.float32, "fp32", "f32", "float32", None):
-        raise L.MCAVError("compute dtype must be fp32 or bf16, got %r" % (dtype,))
+    split = dtype in SPLIT_NAMES
+    if not bf16 and not split and dtype not in (torch.float32, "fp32", "f32", "float32", None):
+        raise L.MCAVError("compute dtype must be fp32, fp32-split or bf16, got %r" % (dtype,))
     for m in module.modules():
         if hasattr(m, "weight") and getattr(m, "weight") is not None and m.weight.dim() == 4:
-            m._mcav_mma = MMA_BF16 if bf16 else MMA_FP32
+            m._mcav_mma = MMA_BF16 if bf16 else MMA_SPLIT if split else MMA_FP32
             spec = getattr(m, "_mcav_spec", None)
             if spec is not None:
                 spec.mma = m._mcav_mma
@@ -344,10 +365,13 @@ def stats_blocks_stem(spec, stats):
 
 def _weights_for(spec, d, transposed):
     """Fills d.w / d.w16 / d.mma of an IgemmDesc whose geometry is already set: the bf16 copy where the launch runs on the bf16 kernels."""
-    if spec.mma == MMA_BF16:
-        d.mma, d.w16, d.w = 1, d.x1, d.x1                 # placeholders: the eligibility test looks at the geometry only
+    if spec.mma in (MMA_BF16, MMA_SPLIT):
+        d.mma, d.w16, d.w = spec.mma, d.x1, d.x1          # placeholders: the eligibility test looks at the geometry only
         if L.lib().mcav_igemm_uses_bf16(ctypes.byref(d)):
-            w16 = spec.packed_bwd16() if transposed else spec.packed_fwd16()
+            if spec.mma == MMA_SPLIT:
+                w16 = spec.packed_bwd16s() if transposed else spec.packed_fwd16s()
+            else:
+                w16 = spec.packed_bwd16() if transposed else spec.packed_fwd16()
             d.w16 = d.w = P(w16)                           # (w is never read on the bf16 path; it only has to be non-null)
             return
     d.mma, d.w16 = 0, None
@@ -484,10 +508,10 @@ def _dgrad_upsample_merged(spec, dy, in_shape, c1, dact_aux, dact, addend, tile)
     d.bias, d.act = None, ACT_NONE
     d.tile = tile & 0xff
     d.w = P(spec.packed_upmerge_adj(c1))
-    if spec.mma == MMA_BF16:
-        d.mma, d.w16 = 1, d.w
+    if spec.mma in (MMA_BF16, MMA_SPLIT):
+        d.mma, d.w16 = spec.mma, d.w
         if L.lib().mcav_igemm_uses_bf16(ctypes.byref(d)):
-            d.w16 = P(spec.packed_upmerge_adj(c1, bf16=True))
+            d.w16 = P(spec.packed_upmerge_adj(c1, bf16=3 if spec.mma == MMA_SPLIT else True))
         else:
             d.mma, d.w16 = 0, None
     with _Timed("dgrad", 2.0 * B * Hd * Wd * spec.cout * c1 * 9,
@@ -515,7 +539,7 @@ def conv_wgrad(spec, x1, dy, x2=None, up1=False, tile=0):
     d.Cout, d.Cin = spec.cout, spec.cin
     d.dw_oihw, d.accumulate, d.dbias = P(gw), 1, P(gb)
     d.tile = tile
-    d.mma = 1 if spec.mma == MMA_BF16 else 0
+    d.mma = spec.mma if spec.mma in (MMA_BF16, MMA_SPLIT) else 0
     bf16 = bool(d.mma and L.lib().mcav_wgrad_uses_bf16(ctypes.byref(d)))
     flops = 2.0 * B * dy.shape[1] * dy.shape[2] * spec.cout * spec.cin * spec.kh * spec.kw
     tag = "pix=%d Cout=%d Ktot=%dx%d s%d" % (B * dy.shape[1] * dy.shape[2], spec.cout, spec.cin, spec.kh * spec.kw, spec.stride)
