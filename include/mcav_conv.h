@@ -80,10 +80,13 @@ typedef struct mcav_igemm_desc {
                              * a = h + m + l (h = bf16(a), m = bf16(a - h), l = bf16(a - h - m); the remainder is below 2^-26 |a|) and the six plane
                              * products hh, hm, mh, hl, lh, mm are accumulated in fp32 (dropped: ml, lm, ll <= 2^-26 of a product).  Same launches
                              * as mma = 1, result at least as exact as the fp32 MFMA's (profiles/r03_mfma_split_exactness.txt) at 6 / 16 of its
-                             * MFMA time. */
+                             * MFMA time.  Runs where it pays: the 3x3 stride-1 zero-padded convolutions and their data gradients (patch-in-LDS
+                             * kernel: operands converted once per chunk); every other launch takes the fp32 kernels with w.
+                             * 3 = as 2, on every launch mma = 1 covers (the table-driven kernels convert per tap: measured no faster than the
+                             * fp32 MFMA kernels; kept for the parity tests). */
     const void* w16;        /* mma = 1: bf16 copy of the packed filter, same [Np][kh*kw][Kp] layout and row stride in ELEMENTS
                              * (mcav_pack_weights_multi with transposed | 2, or mcav_f32_to_bf16 of a packed fp32 copy).
-                             * mma = 2: three such copies back to back, the planes h, m, l of the packed filter, Np * Kstride elements each
+                             * mma = 2 / 3: three such copies back to back, the planes h, m, l of the packed filter, Np * Kstride elements each
                              * (mcav_pack_weights_multi with transposed | 4, or mcav_f32_to_bf16_planes of a packed fp32 copy) */
     /* BatchNorm BACKWARD statistics in the epilogue of the data gradient that produces dy (round 3; with `stats`): when stats_x is set the
      * second statistic of a column is the sum of y * xhat, xhat = (stats_x - stats_mean[g][n]) * stats_invstd[g][n], instead of the sum of
@@ -129,7 +132,7 @@ typedef struct mcav_wgrad_desc {
     int upm, Cin_total, ci_offset;
     int mma;                /* 1: both operands rounded to bf16, reduction over pixels on the bf16 MFMA, fp32 slab / gradient (launches with
                              * >= 32 output channels and 16-channel-aligned sources; others run the fp32 kernels).
-                             * 2: the same launches as an fp32 contraction on three bf16 planes per operand (mcav_igemm_desc.mma = 2) */
+                             * 2 / 3: the same launches as an fp32 contraction on three bf16 planes per operand (mcav_igemm_desc.mma = 2) */
 } mcav_wgrad_desc;
 
 size_t mcav_wgrad_workspace_bytes(const mcav_wgrad_desc* d);

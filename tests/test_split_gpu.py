@@ -47,7 +47,7 @@ def test_split_conv_fwd_dgrad_wgrad_match_float64_as_the_fp32_kernels_do(case):
     xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
     ref_conv64(xr, wr, None, stride, pad, pad_mode).backward(dy.double())
     errs = {}
-    for name, mma in (("fp32", N.MMA_FP32), ("split", N.MMA_SPLIT)):
+    for name, mma in (("fp32", N.MMA_FP32), ("split", N.MMA_SPLIT_ALL)):
         spec = spec_of(w, b, stride, pad, pad_mode, mma)
         y = N.conv_fwd(spec, xin)
         dx = N.conv_dgrad(spec, nhwc(dy), (H, W))
@@ -56,7 +56,7 @@ def test_split_conv_fwd_dgrad_wgrad_match_float64_as_the_fp32_kernels_do(case):
         N.conv_wgrad(spec, xin, nhwc(dy))                   # accumulates
         errs[name] = (rel_err(nchw(y), want), rel_err(nchw(dx), xr.grad), rel_err(g1, wr.grad), rel_err(spec.weight.grad, 2 * wr.grad),
                       rel_err(spec.bias.grad, 2 * dy.double().sum((0, 2, 3))))
-        if mma == N.MMA_SPLIT:
+        if mma == N.MMA_SPLIT_ALL:
             assert "f16s" in spec._packs and "b16s" in spec._packs, "the launches did not take the split kernels"
             assert spec._packs["f16s"].dtype == torch.bfloat16 and spec._packs["f16s"].shape[0] == 3 * spec.np
     print("split vs fp32 kernels against float64 %s: fwd %.2e / %.2e, dgrad %.2e / %.2e, wgrad %.2e / %.2e" %
@@ -71,7 +71,7 @@ def test_split_filter_planes_add_up_to_the_filter():
     from mcav import nn as N
     g = torch.Generator().manual_seed(3)
     w = torch.randn(96, 80, 3, 3, generator=g) * torch.exp(2.0 * torch.randn(96, 80, 1, 1, generator=g))
-    spec = spec_of(w, None, 1, 1, 0, N.MMA_SPLIT)
+    spec = spec_of(w, None, 1, 1, 0, N.MMA_SPLIT_ALL)
     for kind32, kind16 in (("f", "f16s"), ("b", "b16s")):
         for rnd in range(2):
             f32 = spec._packed(kind32).double()
@@ -112,7 +112,7 @@ def test_split_decoder_level_fused_upsample_concat():
     skip = torch.randn(B, C2, 2 * h, 2 * w_, generator=g)
     wt = torch.randn(Cout, C1 + C2, 3, 3, generator=g) * 0.05
     bs = 0.1 * torch.randn(Cout, generator=g)
-    spec = spec_of(wt, bs, 1, 1, 1, N.MMA_SPLIT)
+    spec = spec_of(wt, bs, 1, 1, 1, N.MMA_SPLIT_ALL)
     ar, sr, wr = a.double().requires_grad_(), skip.double().requires_grad_(), wt.double().requires_grad_()
     xcat = torch.cat([F.interpolate(ar, scale_factor=2, mode="nearest"), sr], 1)
     pre = F.conv2d(F.pad(xcat, (1, 1, 1, 1), mode="reflect"), wr, bs.double())

@@ -389,14 +389,18 @@ struct PatchGeo {
 constexpr int PATCH_PIX = 104;      // (TH + 2) (TW + 2) <= 104: 8 x 8 -> 100, 6 x 10 -> 96, 4 x 16 -> 108 is not allowed
 
 template <int NS>
-__global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(IgemmParams p, const u16* __restrict__ w16, PatchGeo geo) {
+__global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, const u16* __restrict__ w16, PatchGeo geo) {
     using T = BT64x64k32;
     constexpr int BM = 64, BN = 64, CKT = 32, LDH = T::LDH;
-    __shared__ __attribute__((aligned(16))) u16 Ap[NS][PATCH_PIX][LDH];
-    __shared__ __attribute__((aligned(16))) u16 Bs[NS][BN][LDH];
-    __shared__ int s_out[BM];
-    float (*const s_stat)[2][BN] = reinterpret_cast<float (*)[2][BN]>(&Bs[0][0][0]);
-    static_assert(sizeof(u16) * BN * LDH >= sizeof(float) * T::WAVES_M * 2 * BN, "statistics scratch fits a filter plane");
+    constexpr int APL = PATCH_PIX * LDH, BPL = BN * LDH;         // plane strides in elements
+    // dynamic LDS (71 KB in the split form: two workgroups per CU): the patch planes, the filter tiles of ONE FILTER ROW (three taps x planes),
+    // the rows' output offsets.  A stage = one filter row of one chunk: 36 MFMAs per wavefront between two barriers.
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    u16* const Ap = reinterpret_cast<u16*>(s_raw);                                     // [NS][PATCH_PIX][LDH]
+    u16* const Bs = Ap + NS * APL;                                                     // [3 taps][NS][BN][LDH]
+    unsigned* const s_out = reinterpret_cast<unsigned*>(Bs + 3 * NS * BPL);            // [BM] byte offset of each row's output pixel (OOB: none)
+    float (*const s_stat)[2][BN] = reinterpret_cast<float (*)[2][BN]>(Bs);
+    static_assert(sizeof(u16) * BPL >= sizeof(float) * T::WAVES_M * 2 * BN, "statistics scratch fits a filter plane");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(IgemmParams p, co
     if (tid < BM) {
         const int py = tid / TW, px = tid - py * TW;
         const int y = ty0 + py, x = tx0 + px;
-        s_out[tid] = (py < TH && y < p.Hd && x < p.Wd) ? (img * p.Hd + y) * p.Wd + x : -1;
+        s_out[tid] = (py < TH && y < p.Hd && x < p.Wd) ? (unsigned)((img * p.Hd + y) * p.Wd + x) * (unsigned)(p.Cd * 4) : OOB;
     }
     // patch staging: thread -> (patch pixel pp0 + 32 j, 4 channels c4); a pixel outside the image reads as zero (the padding)
     const int c4 = tid & 7, pp0 = tid >> 3;
@@ -441,28 +445,36 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(IgemmParams p, co
         for (int j = 0; j < 4; ++j) {
             const int pp = pp0 + 32 * j;
             if (pp < PATCH_PIX) {
+                u16* const dst = Ap + pp * LDH + c4 * 4;
                 if constexpr (NS == 1) {
-                    *reinterpret_cast<u32x2*>(&Ap[0][pp][c4 * 4]) = pack_bf16x4(ra[j]);
+                    *reinterpret_cast<u32x2*>(dst) = pack_bf16x4(ra[j]);
                 } else {
                     const bf16x4 h = __builtin_convertvector(ra[j], bf16x4);
                     const f32x4 r1 = ra[j] - __builtin_convertvector(h, f32x4);            // exact
                     const bf16x4 m = __builtin_convertvector(r1, bf16x4);
                     const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);               // exact
-                    *reinterpret_cast<u32x2*>(&Ap[0][pp][c4 * 4]) = __builtin_bit_cast(u32x2, h);
-                    *reinterpret_cast<u32x2*>(&Ap[1][pp][c4 * 4]) = __builtin_bit_cast(u32x2, m);
-                    *reinterpret_cast<u32x2*>(&Ap[2][pp][c4 * 4]) = pack_bf16x4(r2);
+                    *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, h);
+                    *reinterpret_cast<u32x2*>(dst + APL) = __builtin_bit_cast(u32x2, m);
+                    *reinterpret_cast<u32x2*>(dst + 2 * APL) = pack_bf16x4(r2);
                 }
             }
         }
     };
-    auto issueB = [&](f32x4 (&rb)[NS], int chunk, int tap) {
-        const int kb = (tap * p.Kp + chunk * CKT) * 2;
+    // stage s = chunk * 3 + ky: the filter tiles of taps (ky, 0..2) x planes
+    auto issueB = [&](f32x4 (&rb)[3][NS], int s) {
+        const int chunk = s / 3, ky = s - chunk * 3;
 #pragma unroll
-        for (int q = 0; q < NS; ++q) rb[q] = buf_load4s(rsw, boff, kb + q * (int)plane_bytes);
+        for (int kx = 0; kx < 3; ++kx) {
+            const int kb = ((ky * 3 + kx) * p.Kp + chunk * CKT) * 2;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) rb[kx][q] = buf_load4s(rsw, boff, kb + q * (int)plane_bytes);
+        }
     };
-    auto storeB = [&](const f32x4 (&rb)[NS]) {
+    auto storeB = [&](const f32x4 (&rb)[3][NS]) {
 #pragma unroll
-        for (int q = 0; q < NS; ++q) *reinterpret_cast<f32x4*>(&Bs[q][bn][bcb * 8]) = rb[q];
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) *reinterpret_cast<f32x4*>(Bs + (kx * NS + q) * BPL + bn * LDH + bcb * 8) = rb[kx][q];
     };
 
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
@@ -477,20 +489,31 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(IgemmParams p, co
         const int py = r / TW, px = r - py * TW;
         prow = py < TH ? py * PW + px : 0;                       // rows past the block multiply pixel 0 (their results are dropped)
     }
-    const u16* const a_lane = &Ap[0][prow][fk];
-    const u16* const b_lane = &Bs[0][wn0 + frow][fk];
-    constexpr int APL = PATCH_PIX * LDH, BPL = BN * LDH;         // plane strides in elements
-    auto compute = [&](int tap) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int shift = __builtin_amdgcn_readfirstlane((g.sign > 0 ? ky * PW + kx : (2 - ky) * PW + (2 - kx)) * LDH);
-#pragma unroll
-        for (int ks = 0; ks < CKT / 16; ++ks) {
-            bf16x8 a[NS], b[NS];
+    const u16* const a_lane = Ap + prow * LDH + fk;
+    const u16* const b_lane = Bs + (wn0 + frow) * LDH + fk;
+    const bool fwd = g.sign > 0;
+    // A stage's six steps (three taps x two 16-deep k-steps), software-pipelined by hand: the fragments of step i + 1 are read from LDS while
+    // the MFMAs of step i run (left to itself the compiler waits for each ds_read right in front of the MFMA that uses it).
+    auto compute = [&](int ky) {
+        const int rowshift = __builtin_amdgcn_readfirstlane((fwd ? ky : 2 - ky) * PW * LDH);
+        const int dxs = __builtin_amdgcn_readfirstlane(fwd ? LDH : -LDH);
+        const u16* const a_row = a_lane + rowshift + (fwd ? 0 : 2 * LDH);
+        bf16x8 fa[2][NS], fb[2][NS];
+        auto load = [&](int i, bf16x8 (&a)[NS], bf16x8 (&b)[NS]) {
+            const int kx = i >> 1, ks = i & 1;
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                a[q] = *reinterpret_cast<const bf16x8*>(a_lane + q * APL + shift + ks * 16);
-                b[q] = *reinterpret_cast<const bf16x8*>(b_lane + q * BPL + ks * 16);
+                a[q] = *reinterpret_cast<const bf16x8*>(a_row + q * APL + kx * dxs + ks * 16);
+                b[q] = *reinterpret_cast<const bf16x8*>(b_lane + (kx * NS + q) * BPL + ks * 16);
             }
+        };
+        load(0, fa[0], fb[0]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i + 1 < 6) load(i + 1, fa[(i + 1) & 1], fb[(i + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8(&a)[NS] = fa[i & 1];
+            const bf16x8(&b)[NS] = fb[i & 1];
             if constexpr (NS == 1) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[0][0], 0, 0, 0);
             } else {
@@ -501,33 +524,38 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(IgemmParams p, co
                 mid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], mid, 0, 0, 0);
                 low = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], low, 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    f32x4 ra[4], rb[NS];
+    f32x4 ra[4], rb[3][NS];
+    const int total = nchunks * 3;
     issueA(ra, 0);
-    issueB(rb, 0, 0);
+    issueB(rb, 0);
     storeA(ra);
     storeB(rb);
+    if (total > 1) issueB(rb, 1);
     __syncthreads();
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    int ky = 0, chunk = 0;
+    for (int s = 0; s < total; ++s) {
         const bool more = chunk + 1 < nchunks;
-        if (more) issueA(ra, chunk + 1);                          // lands during the nine taps below
-        for (int tap = 0; tap < 9; ++tap) {
-            const bool nextB = tap < 8 || more;
-            if (nextB) issueB(rb, tap < 8 ? chunk : chunk + 1, tap < 8 ? tap + 1 : 0);
-            compute(tap);
+        if (ky == 0 && more) issueA(ra, chunk + 1);               // lands during the chunk's three stages
+        compute(ky);
+        __syncthreads();
+        if (ky == 2 && more) storeA(ra);
+        if (s + 1 < total) {
+            storeB(rb);                                           // stage s + 1 (in flight since the end of stage s - 1)
+            if (s + 2 < total) issueB(rb, s + 2);
             __syncthreads();
-            if (tap == 8 && more) storeA(ra);
-            if (nextB) {
-                storeB(rb);
-                __syncthreads();
-            }
         }
+        if (++ky == 3) { ky = 0; ++chunk; }
     }
     if constexpr (NS > 1) acc[0][0] += mid + low;
-    igemm_epilogue<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
+    igemm_epilogue_lean<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
 }
+
+template <int NS>
+constexpr size_t patch_lds_bytes() { return sizeof(u16) * (size_t)NS * (PATCH_PIX + 3 * 64) * BT64x64k32::LDH + sizeof(unsigned) * 64; }
 
 // The block shape for an H x W map: TH TW <= 64 rows, (TH + 2)(TW + 2) <= PATCH_PIX, fewest wasted rows, then the smallest halo.
 static void patch_block(int H, int W, int& TH, int& TW) {
@@ -545,7 +573,7 @@ static void patch_block(int H, int W, int& TH, int& TW) {
 // 1 = the descriptor runs on conv3x3_patch_kernel (fills geo): a 3x3 stride-1 zero-padded convolution or its data gradient, one source
 static bool patch_plan(const mcav_igemm_desc* d, PatchGeo& geo) {
     static const int enabled = [] { const char* e = getenv("MCAV_PATCH"); return e ? atoi(e) : 1; }();
-    if (!enabled || !d || !d->w16 || (d->mma != 1 && d->mma != 2)) return false;
+    if (!enabled || !d || !d->w16 || (d->mma < 1 || d->mma > 3)) return false;
     if (d->mode != MCAV_G_DIRECT || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_mode != MCAV_PAD_ZERO) return false;
     if (!((d->sign == 1 && d->offset == -1) || (d->sign == -1 && d->offset == 1))) return false;
     if (d->C2 != 0 || d->up1 || d->pool || d->w_upmerge) return false;
@@ -554,6 +582,8 @@ static bool patch_plan(const mcav_igemm_desc* d, PatchGeo& geo) {
     patch_block(d->Hd, d->Wd, geo.TH, geo.TW);
     geo.tiles_y = (d->Hd + geo.TH - 1) / geo.TH;
     geo.tiles_x = (d->Wd + geo.TW - 1) / geo.TW;
+    // plain bf16 on few blocks (the 6x20 maps): the table-driven 32x64 tiles are faster (0.043 against 0.055 ms on 512 -> 512)
+    if (d->mma == 1 && (long)d->B * geo.tiles_y * geo.tiles_x * ((d->n_count + 63) / 64) < 1024) return false;
     return true;
 }
 
@@ -569,7 +599,7 @@ __device__ __forceinline__ int wsw(int row, int kb) { return ((kb ^ ((row >> 1) 
 // NS = 3: the fp32 contraction on split operands (see igemm_bf16_kernel): both operands are split on their way into LDS, one panel of
 // three planes each, half the offset-table capacity (52 KB of LDS: three workgroups per CU).
 template <int NS>
-__global__ __launch_bounds__(256, NS == 3 ? 3 : 2) void wgrad_bf16_kernel(WgradParams p) {
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradParams p) {
     constexpr int BM = 64, BN = 64;
     constexpr int NB = NS == 1 ? 2 : 1;
     __shared__ __attribute__((aligned(16))) u16 Xs[NB * NS][BM][KPB];      // [kflat row][64 pixels], 128-byte rows, 16-byte slots XOR-swizzled
@@ -757,20 +787,11 @@ __global__ __launch_bounds__(256, NS == 3 ? 3 : 2) void wgrad_bf16_kernel(WgradP
         if (((tt + 1) & ((1 << cht) - 1)) == 0 && ((tt + 1) >> cht) + 1 < nchunks) build_chunk(((tt + 1) >> cht) + 1);
     };
 
-    f32x4 rv[8], rv2[NS == 1 ? 1 : 8];
-    if constexpr (NS == 1) {
-        if (T_total > 0) {
-            issue(rv);
-            store(rv, B0{});
-            if (T_total > 1) issue(rv);
-        }
-    } else {
-        if (T_total > 0) {
-            issue(rv);
-            if (T_total > 1) issue(rv2);
-            store(rv, B0{});
-            if (T_total > 2) issue(rv);
-        }
+    f32x4 rv[8];
+    if (T_total > 0) {
+        issue(rv);
+        store(rv, B0{});
+        if (T_total > 1) issue(rv);
     }
     __syncthreads();
     if constexpr (NS == 1) {
@@ -794,23 +815,16 @@ __global__ __launch_bounds__(256, NS == 3 ? 3 : 2) void wgrad_bf16_kernel(WgradP
             __syncthreads();
         }
     } else {
-        // two register stages: tiles t + 1 and t + 2 in flight while tile t is multiplied (see igemm_bf16_kernel)
-        for (int t = 0; t < T_total; t += 2) {
+        // one panel: multiply tile t, barrier, write tile t + 1 (its loads were in flight during the multiply), issue tile t + 2, barrier
+        // (a second register stage was measured: 176 registers, two wavefronts per SIMD, slower)
+        for (int t = 0; t < T_total; ++t) {
             maybe_build(t);
             compute(B0{});
             __syncthreads();
             if (t + 1 < T_total) {
-                store(rv2, B0{});
-                if (t + 3 < T_total) issue(rv2);
+                store(rv, B0{});
+                if (t + 2 < T_total) issue(rv);
                 __syncthreads();
-                maybe_build(t + 1);
-                compute(B0{});
-                __syncthreads();
-                if (t + 2 < T_total) {
-                    store(rv, B0{});
-                    if (t + 4 < T_total) issue(rv);
-                    __syncthreads();
-                }
             }
         }
         acc += mid + low;
@@ -849,7 +863,13 @@ inline void launch_igemm_bf16(const IgemmParams& p, const void* w16, bool refl, 
 
 // Which bf16 tile (0 = the launch is not one the bf16 kernels cover: the caller runs the fp32 path).  Sets *refl.
 static int bf16_tile_for(const mcav_igemm_desc* d, bool* refl) {
-    if (!d || !d->w16 || (d->mma != 1 && d->mma != 2)) return 0;
+    if (!d || !d->w16 || (d->mma < 1 || d->mma > 3)) return 0;
+    if (d->mma == 2) {
+        // The split form pays where the contraction dominates and the operands are converted once: the patch kernel.  On the table-driven
+        // kernels (a conversion per tap) it was measured level with or behind the fp32 MFMA kernels (mma = 3 runs those too: tests).
+        PatchGeo geo;
+        if (!patch_plan(d, geo)) return 0;
+    }
     if (d->pool || d->w_upmerge) return 0;                            // pooled / merged-tap forms stay on the fp32 kernels
     if (d->kh * d->kw > TAB_TAPS || d->Kp % 32 != 0 || d->C1 + d->C2 != d->Kp) return 0;
     if ((d->C1 & 3) || (d->C2 & 3) || (d->C2 > 0 && d->C1 % 32 != 0)) return 0;
@@ -865,7 +885,7 @@ static int bf16_tile_for(const mcav_igemm_desc* d, bool* refl) {
     int shape = 10;                                                   // 64 x 64
     if (wg64 >= 4096 && !radj) shape = 8;                             // many rows: 128 x 64 (half the filter re-reads)
     else if (wg64 < 512) shape = 12;                                  // few rows (6x20 maps): 32 x 64
-    if (d->mma == 2) {
+    if (d->mma >= 2) {
         static const int forced = [] { const char* e = getenv("MCAV_SPLIT_TILE"); return e ? atoi(e) : 0; }();      // tuning knob: 10 / 8 / 12
         if ((forced == 10 || forced == 12 || (forced == 8 && !radj))) shape = forced;
     }
@@ -891,17 +911,26 @@ int mcav_bf16_igemm(const mcav_igemm_desc* d, hipStream_t s) {
     if (patch_plan(d, geo)) {
         dd.tile = 10;
         if (!fill_params(&dd, p, tile) || p.upm) return MCAV_E_INVALID;
-        if ((long)d->Np * p.Kstride * 2 * (d->mma == 2 ? 3 : 1) >= 0x7fffffffL) return MCAV_E_INVALID;
+        if ((long)d->Np * p.Kstride * 2 * (d->mma >= 2 ? 3 : 1) >= 0x7fffffffL) return MCAV_E_INVALID;
         p.mtiles = d->B * geo.tiles_y * geo.tiles_x;                  // rows of the statistics slab = blocks, image-major (groups = runs of images)
         p.ntiles = (p.n_count + 63) / 64;
-        if (d->mma == 2) timed_launch(conv3x3_patch_kernel<3>, p.mtiles * p.ntiles, dim3(256), 0, s, p, reinterpret_cast<const u16*>(d->w16), geo);
-        else timed_launch(conv3x3_patch_kernel<1>, p.mtiles * p.ntiles, dim3(256), 0, s, p, reinterpret_cast<const u16*>(d->w16), geo);
+        // (more than 64 KB of dynamic LDS has to be allowed once per kernel)
+        static const bool allowed = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)patch_lds_bytes<3>()) == hipSuccess;
+        }();
+        if (d->mma >= 2) {
+            if (!allowed) return MCAV_E_LAUNCH;
+            timed_launch(conv3x3_patch_kernel<3>, p.mtiles * p.ntiles, dim3(256), patch_lds_bytes<3>(), s, p, reinterpret_cast<const u16*>(d->w16), geo);
+        } else {
+            timed_launch(conv3x3_patch_kernel<1>, p.mtiles * p.ntiles, dim3(256), patch_lds_bytes<1>(), s, p, reinterpret_cast<const u16*>(d->w16), geo);
+        }
         return launch_status();
     }
     if (!fill_params(&dd, p, tile) || p.upm) return MCAV_E_INVALID;
     if ((long)d->Np * p.Kstride * 2 >= 0x7fffffffL) return MCAV_E_INVALID;
     const bool k64 = bt & 1;
-    if (d->mma == 2) {
+    if (d->mma >= 2) {
         if ((long)d->Np * p.Kstride * 2 * 3 >= 0x7fffffffL) return MCAV_E_INVALID;
         switch (tile) {
             case 10: launch_igemm_bf16<BT64x64k32, 3>(p, d->w16, refl, s); break;
@@ -944,7 +973,7 @@ MCAV_EXPORT int mcav_igemm_uses_bf16(const mcav_igemm_desc* d) {
 
 // Plans the bf16 weight-gradient launch into pl (splits over 64-pixel K-tiles, table chunking); false = not eligible.
 bool mcav_bf16_wgrad_plan(const mcav_wgrad_desc* d, WgradPlan& pl) {
-    if (!d || (d->mma != 1 && d->mma != 2) || d->upm) return false;
+    if (!d || (d->mma < 1 || d->mma > 3) || d->upm) return false;
     if (d->mode != MCAV_G_DIRECT || d->Kp % 16 != 0 || d->C1 + d->C2 != d->Kp || d->Cin != d->Kp) return false;
     if ((d->C1 & 15) || (d->C2 & 15) || d->Cout < 32 || (d->Cdy & 3) || (d->dy_choff & 3)) return false;
     mcav_wgrad_desc dd = *d;
@@ -980,14 +1009,14 @@ bool mcav_bf16_wgrad_plan(const mcav_wgrad_desc* d, WgradPlan& pl) {
     }
     const int epp = ntmax * (d->C2 > 0 ? 2 : 1);
     p.tab_cht_log2 = 20;
-    const int tabcap = d->mma == 2 ? WG_TABCAP / 2 : WG_TABCAP;       // (the split form gives half of the table's LDS to its planes)
+    const int tabcap = d->mma >= 2 ? WG_TABCAP / 2 : WG_TABCAP;       // (the split form gives half of the table's LDS to its planes)
     if ((long)p.pix_per_split * epp > tabcap) {
         if (2 * 2 * KPB * epp > tabcap) return false;                 // not even two 2-tile chunks fit
         int lg = 1;
         while ((2 << lg) * KPB * epp <= tabcap / 2) ++lg;
         p.tab_cht_log2 = lg;
     }
-    p.split_planes = d->mma == 2;
+    p.split_planes = d->mma >= 2;
     pl.use_tab = true;
     pl.slab_bytes = align_up(sizeof(float) * (size_t)p.splits * (p.Ktot + 1) * p.slabN, 256);
     pl.groups = p.splits > 8 ? 8 : 0;

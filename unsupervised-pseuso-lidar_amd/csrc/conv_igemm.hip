@@ -1915,7 +1915,7 @@ MCAV_EXPORT int mcav_igemm_mtiles(const mcav_igemm_desc* d) {
     int tile;
     if (!fill_params(d, p, tile)) return MCAV_E_INVALID;
     if (const int st = mcav_stem_mtiles(d)) return st;             // the stem kernel's 8 x 32 output tiles
-    if (d->mma == 1 || d->mma == 2) {                              // the bf16 kernels choose their own tile shape
+    if (d->mma != 0) {                              // the bf16 kernels choose their own tile shape
         const int mt = mcav_bf16_igemm_mtiles(d);
         if (mt > 0) return mt;
     }
@@ -1936,7 +1936,7 @@ MCAV_EXPORT int mcav_igemm(const mcav_igemm_desc* d, void* stream) {
     hipStream_t s = as_stream(stream);
     if (mcav_try_halo(d, s)) return launch_status();
     if (mcav_try_stem(d, p, s)) return launch_status();
-    if (d->mma == 1 || d->mma == 2) {                    // bf16 MFMA tiles (conv_bf16.hip) where the launch qualifies, else the fp32 kernels below
+    if (d->mma != 0) {                    // bf16 MFMA tiles (conv_bf16.hip) where the launch qualifies, else the fp32 kernels below
         const int rc = mcav_bf16_igemm(d, s);
         if (rc != 1) return rc;
     }

@@ -156,7 +156,7 @@ class _PackItem(ctypes.Structure):
                 ("Kstride", c_i), ("first_block", c_i)]
 
 
-MMA_FP32, MMA_BF16, MMA_SPLIT = 0, 1, 2
+MMA_FP32, MMA_BF16, MMA_SPLIT, MMA_SPLIT_ALL = 0, 1, 2, 3      # (3: the split form on every launch the bf16 kernels cover, not only where it pays: tests)
 # kind -> (transposed, bf16 planes: 0 = an fp32 copy, 1 = bf16, 3 = the planes h, m, l of the fp32 contraction on split operands)
 _KINDS = {"f": (False, 0), "b": (True, 0), "f16": (False, 1), "b16": (True, 1), "f16s": (False, 3), "b16s": (True, 3)}
 
@@ -337,6 +337,8 @@ class ConvSpec:
         return self._upa16
 
 
+# MMA_SPLIT weight gradients: 1 = on the split kernel (wgrad_bf16_kernel<3>), 0 = on the fp32-MFMA kernel (both are fp32 results)
+SPLIT_WGRAD = _os.environ.get("MCAV_SPLIT_WGRAD", "0") != "0"
 SPLIT_NAMES = ("fp32-split", "fp32_split", "f32s", "fp32s")
 
 
@@ -365,10 +367,10 @@ def stats_blocks_stem(spec, stats):
 
 def _weights_for(spec, d, transposed):
     """Fills d.w / d.w16 / d.mma of an IgemmDesc whose geometry is already set: the bf16 copy where the launch runs on the bf16 kernels."""
-    if spec.mma in (MMA_BF16, MMA_SPLIT):
+    if spec.mma in (MMA_BF16, MMA_SPLIT, MMA_SPLIT_ALL):
         d.mma, d.w16, d.w = spec.mma, d.x1, d.x1          # placeholders: the eligibility test looks at the geometry only
         if L.lib().mcav_igemm_uses_bf16(ctypes.byref(d)):
-            if spec.mma == MMA_SPLIT:
+            if spec.mma >= MMA_SPLIT:
                 w16 = spec.packed_bwd16s() if transposed else spec.packed_fwd16s()
             else:
                 w16 = spec.packed_bwd16() if transposed else spec.packed_fwd16()
@@ -508,10 +510,10 @@ def _dgrad_upsample_merged(spec, dy, in_shape, c1, dact_aux, dact, addend, tile)
     d.bias, d.act = None, ACT_NONE
     d.tile = tile & 0xff
     d.w = P(spec.packed_upmerge_adj(c1))
-    if spec.mma in (MMA_BF16, MMA_SPLIT):
+    if spec.mma in (MMA_BF16, MMA_SPLIT, MMA_SPLIT_ALL):
         d.mma, d.w16 = spec.mma, d.w
         if L.lib().mcav_igemm_uses_bf16(ctypes.byref(d)):
-            d.w16 = P(spec.packed_upmerge_adj(c1, bf16=3 if spec.mma == MMA_SPLIT else True))
+            d.w16 = P(spec.packed_upmerge_adj(c1, bf16=3 if spec.mma >= MMA_SPLIT else True))
         else:
             d.mma, d.w16 = 0, None
     with _Timed("dgrad", 2.0 * B * Hd * Wd * spec.cout * c1 * 9,
@@ -539,7 +541,7 @@ def conv_wgrad(spec, x1, dy, x2=None, up1=False, tile=0):
     d.Cout, d.Cin = spec.cout, spec.cin
     d.dw_oihw, d.accumulate, d.dbias = P(gw), 1, P(gb)
     d.tile = tile
-    d.mma = spec.mma if spec.mma in (MMA_BF16, MMA_SPLIT) else 0
+    d.mma = spec.mma if (spec.mma in (MMA_BF16, MMA_SPLIT_ALL) or (spec.mma == MMA_SPLIT and SPLIT_WGRAD)) else 0
     bf16 = bool(d.mma and L.lib().mcav_wgrad_uses_bf16(ctypes.byref(d)))
     flops = 2.0 * B * dy.shape[1] * dy.shape[2] * spec.cout * spec.cin * spec.kh * spec.kw
     tag = "pix=%d Cout=%d Ktot=%dx%d s%d" % (B * dy.shape[1] * dy.shape[2], spec.cout, spec.cin, spec.kh * spec.kw, spec.stride)
