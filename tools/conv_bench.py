@@ -56,7 +56,10 @@ def main():
             tiles = [int(t, 0) for t in a.split("=")[1].split(",")]
     dev = "cuda"
     batch = int(os.environ.get("CONV_BENCH_BATCH", "0"))      # 24 = the stacked tgt/ref0 passes of the step
-    for (B, H, W, Cin, Cout, k, s, p, pm) in SHAPES:
+    only = [int(t) for t in os.environ.get("CONV_BENCH_SHAPES", "").split(",") if t]      # indices into SHAPES (PMC runs: one shape)
+    for si, (B, H, W, Cin, Cout, k, s, p, pm) in enumerate(SHAPES):
+        if only and si not in only:
+            continue
         B = batch or B
         w = torch.nn.Parameter(torch.randn(Cout, Cin, k, k, device=dev) * 0.05)
         b = torch.nn.Parameter(torch.zeros(Cout, device=dev))

@@ -382,16 +382,30 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p, const u1
 // at 8 x 8 instead of 9x), the nine taps are nine shifted views of the patch -- a tap is a constant added to each lane's patch row --, and
 // only the filter tile of the tap (64 outputs x 32 channels per plane, L2-resident) is streamed.  The next chunk's patch is in flight
 // during the nine taps of the current one, the next tap's filter tile during the current tap's MFMAs.
+// GEMM row R (0..63) of a block -> linear pixel index: the 16 lanes of a ds_read_b128 group ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of each
+// 32-row half) get 16 consecutive pixels.
+__device__ __forceinline__ int patch_pixel(int R) {
+    const int r = R & 31;
+    const bool g0 = r < 4 || (r >= 12 && r < 16) || (r >= 20 && r < 28);
+    const int idx = g0 ? (r < 4 ? r : (r < 16 ? r - 8 : r - 12)) : (r < 12 ? r - 4 : (r < 20 ? r - 8 : r - 16));
+    return (R & 32) + (g0 ? 0 : 16) + idx;
+}
+
 struct PatchGeo {
     int TH, TW, tiles_y, tiles_x;
 };
 
-constexpr int PATCH_PIX = 104;      // (TH + 2) (TW + 2) <= 104: 8 x 8 -> 100, 6 x 10 -> 96, 4 x 16 -> 108 is not allowed
+constexpr int PATCH_PIX = 108;      // (TH + 2) (TW + 2) <= 108: 4 x 16 -> 108, 8 x 8 -> 100, 6 x 10 -> 96
 
 template <int NS>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, const u16* __restrict__ w16, PatchGeo geo) {
     using T = BT64x64k32;
-    constexpr int BM = 64, BN = 64, CKT = 32, LDH = T::LDH;
+    // LDS rows are 64 bytes (32 channels: four rows per 256-byte bank row) with the four 16-byte slots of row r XOR-ed by (r >> 2) & 3: a
+    // ds_read_b128 lane group (16 lanes: MI355X_MICROARCH.md section LDS) is conflict-free when its 16 rows are distinct mod 16.  The
+    // filter rows of a group are (row = lane); for the patch, GEMM row R of the block stands for pixel patch_pixel(R), which gives every
+    // lane group 16 consecutive pixels -- one pixel row of a 16-wide block, whose patch rows are consecutive whatever the tap.  The staging
+    // stores fill whole 64-byte rows (128 bytes per ds_write group).  (Padded 80-byte rows: half of the LDS cycles were bank conflicts.)
+    constexpr int BM = 64, BN = 64, CKT = 32, LDH = 32;
     constexpr int APL = PATCH_PIX * LDH, BPL = BN * LDH;         // plane strides in elements
     // dynamic LDS (71 KB in the split form: two workgroups per CU): the patch planes, the filter tiles of ONE FILTER ROW (three taps x planes),
     // the rows' output offsets.  A stage = one filter row of one chunk: 36 MFMAs per wavefront between two barriers.
@@ -413,7 +427,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
     const int ty0 = (tr / geo.tiles_x) * TH, tx0 = (tr % geo.tiles_x) * TW;
 
     if (tid < BM) {
-        const int py = tid / TW, px = tid - py * TW;
+        const int pix = patch_pixel(tid);
+        const int py = pix / TW, px = pix - py * TW;
         const int y = ty0 + py, x = tx0 + px;
         s_out[tid] = (py < TH && y < p.Hd && x < p.Wd) ? (unsigned)((img * p.Hd + y) * p.Wd + x) * (unsigned)(p.Cd * 4) : OOB;
     }
@@ -445,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
         for (int j = 0; j < 4; ++j) {
             const int pp = pp0 + 32 * j;
             if (pp < PATCH_PIX) {
-                u16* const dst = Ap + pp * LDH + c4 * 4;
+                u16* const dst = Ap + pp * LDH + (((c4 >> 1) ^ ((pp >> 2) & 3)) * 8) + (c4 & 1) * 4;
                 if constexpr (NS == 1) {
                     *reinterpret_cast<u32x2*>(dst) = pack_bf16x4(ra[j]);
                 } else {
@@ -474,37 +489,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int q = 0; q < NS; ++q) *reinterpret_cast<f32x4*>(Bs + (kx * NS + q) * BPL + bn * LDH + bcb * 8) = rb[kx][q];
+            for (int q = 0; q < NS; ++q) *reinterpret_cast<f32x4*>(Bs + (kx * NS + q) * BPL + bn * LDH + ((bcb ^ ((bn >> 2) & 3)) * 8)) = rb[kx][q];
     };
 
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
     typename T::AccT acc[1][1], mid, low;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; mid[r] = 0.f; low[r] = 0.f; }
-    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    const int frow = lane & 31;
     // this lane's A row = output pixel (py, px) of the block -> patch pixel (py + dy, px + dx), dy / dx = the tap (mirrored for the data gradient)
     int prow;
     {
-        const int r = wm0 + frow;
-        const int py = r / TW, px = r - py * TW;
+        const int pix = patch_pixel(wm0 + frow);
+        const int py = pix / TW, px = pix - py * TW;
         prow = py < TH ? py * PW + px : 0;                       // rows past the block multiply pixel 0 (their results are dropped)
     }
-    const u16* const a_lane = Ap + prow * LDH + fk;
-    const u16* const b_lane = Bs + (wn0 + frow) * LDH + fk;
+    const int fslot = lane >> 5;                                  // which 16-byte half of a k-step this lane holds
+    const int brow = wn0 + frow;
+    const u16* const b_lane0 = Bs + brow * LDH + ((fslot ^ ((brow >> 2) & 3)) * 8);            // k-step 0 / 1 of this lane's filter row
+    const u16* const b_lane1 = Bs + brow * LDH + (((2 + fslot) ^ ((brow >> 2) & 3)) * 8);
     const bool fwd = g.sign > 0;
     // A stage's six steps (three taps x two 16-deep k-steps), software-pipelined by hand: the fragments of step i + 1 are read from LDS while
     // the MFMAs of step i run (left to itself the compiler waits for each ds_read right in front of the MFMA that uses it).
     auto compute = [&](int ky) {
-        const int rowshift = __builtin_amdgcn_readfirstlane((fwd ? ky : 2 - ky) * PW * LDH);
-        const int dxs = __builtin_amdgcn_readfirstlane(fwd ? LDH : -LDH);
-        const u16* const a_row = a_lane + rowshift + (fwd ? 0 : 2 * LDH);
+        const int row0 = prow + (fwd ? ky : 2 - ky) * PW + (fwd ? 0 : 2);                  // patch row of tap (ky, 0); tap kx is dxr rows further
+        const int dxr = fwd ? 1 : -1;
         bf16x8 fa[2][NS], fb[2][NS];
         auto load = [&](int i, bf16x8 (&a)[NS], bf16x8 (&b)[NS]) {
             const int kx = i >> 1, ks = i & 1;
+            const int row = row0 + kx * dxr;
+            const u16* const ap = Ap + row * LDH + (((2 * ks + fslot) ^ ((row >> 2) & 3)) * 8);
+            const u16* const bp = (ks ? b_lane1 : b_lane0) + kx * NS * BPL;
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                a[q] = *reinterpret_cast<const bf16x8*>(a_row + q * APL + kx * dxs + ks * 16);
-                b[q] = *reinterpret_cast<const bf16x8*>(b_lane + (kx * NS + q) * BPL + ks * 16);
+                a[q] = *reinterpret_cast<const bf16x8*>(ap + q * APL);
+                b[q] = *reinterpret_cast<const bf16x8*>(bp + q * BPL);
             }
         };
         load(0, fa[0], fb[0]);
@@ -528,34 +547,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
         }
     };
 
-    f32x4 ra[4], rb[3][NS];
+    // The filter tiles are the kernel's traffic (46 KB per stage in the split form against 25 KB of patch per chunk), all of it from L2:
+    // two register stages keep the tiles of stages s + 1 and s + 2 in flight while stage s is multiplied.
+    f32x4 ra[4], rb0[3][NS], rb1[3][NS];
     const int total = nchunks * 3;
     issueA(ra, 0);
-    issueB(rb, 0);
+    issueB(rb0, 0);
     storeA(ra);
-    storeB(rb);
-    if (total > 1) issueB(rb, 1);
+    storeB(rb0);
+    if (total > 1) issueB(rb0, 1);
+    if (total > 2) issueB(rb1, 2);
     __syncthreads();
     int ky = 0, chunk = 0;
-    for (int s = 0; s < total; ++s) {
+    auto stage = [&](int s, f32x4 (&rb_next)[3][NS]) {            // rb_next holds stage s + 1 and is re-issued for stage s + 3
         const bool more = chunk + 1 < nchunks;
         if (ky == 0 && more) issueA(ra, chunk + 1);               // lands during the chunk's three stages
         compute(ky);
         __syncthreads();
         if (ky == 2 && more) storeA(ra);
         if (s + 1 < total) {
-            storeB(rb);                                           // stage s + 1 (in flight since the end of stage s - 1)
-            if (s + 2 < total) issueB(rb, s + 2);
+            storeB(rb_next);
+            if (s + 3 < total) issueB(rb_next, s + 3);
             __syncthreads();
         }
         if (++ky == 3) { ky = 0; ++chunk; }
+    };
+    for (int s = 0; s < total; s += 2) {
+        stage(s, rb0);
+        if (s + 1 < total) stage(s + 1, rb1);
     }
     if constexpr (NS > 1) acc[0][0] += mid + low;
     igemm_epilogue_lean<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
 }
 
 template <int NS>
-constexpr size_t patch_lds_bytes() { return sizeof(u16) * (size_t)NS * (PATCH_PIX + 3 * 64) * BT64x64k32::LDH + sizeof(unsigned) * 64; }
+constexpr size_t patch_lds_bytes() { return sizeof(u16) * (size_t)NS * (PATCH_PIX + 3 * 64) * 32 + sizeof(unsigned) * 64; }
 
 // The block shape for an H x W map: TH TW <= 64 rows, (TH + 2)(TW + 2) <= PATCH_PIX, fewest wasted rows, then the smallest halo.
 static void patch_block(int H, int W, int& TH, int& TW) {
@@ -565,7 +591,8 @@ static void patch_block(int H, int W, int& TH, int& TW) {
         for (int tw = 4; tw <= 64; ++tw) {
             if (th * tw > 64 || (th + 2) * (tw + 2) > PATCH_PIX) continue;
             const double tiles = (double)((H + th - 1) / th) * ((W + tw - 1) / tw);
-            const double cost = tiles * 64.0 * (1.0 + 0.05 * (double)((th + 2) * (tw + 2)) / (th * tw)) * ((tw & 7) ? 1.02 : 1.0);
+            // (16-wide blocks read the patch without bank conflicts: worth some wasted rows)
+            const double cost = tiles * 64.0 * (1.0 + 0.05 * (double)((th + 2) * (tw + 2)) / (th * tw)) * (tw == 16 ? 1.0 : 1.25);
             if (cost < best) { best = cost; TH = th; TW = tw; }
         }
 }
