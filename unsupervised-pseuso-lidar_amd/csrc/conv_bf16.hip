@@ -382,33 +382,43 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p, const u1
 // at 8 x 8 instead of 9x), the nine taps are nine shifted views of the patch -- a tap is a constant added to each lane's patch row --, and
 // only the filter tile of the tap (64 outputs x 32 channels per plane, L2-resident) is streamed.  The next chunk's patch is in flight
 // during the nine taps of the current one, the next tap's filter tile during the current tap's MFMAs.
-// GEMM row R (0..63) of a block -> linear pixel index: the 16 lanes of a ds_read_b128 group ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of each
+// GEMM row R (0..127) of a block -> linear pixel index: the 16 lanes of a ds_read_b128 group ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of each
 // 32-row half) get 16 consecutive pixels.
 __device__ __forceinline__ int patch_pixel(int R) {
     const int r = R & 31;
     const bool g0 = r < 4 || (r >= 12 && r < 16) || (r >= 20 && r < 28);
     const int idx = g0 ? (r < 4 ? r : (r < 16 ? r - 8 : r - 12)) : (r < 12 ? r - 4 : (r < 20 ? r - 8 : r - 16));
-    return (R & 32) + (g0 ? 0 : 16) + idx;
+    return (R & ~31) + (g0 ? 0 : 16) + idx;
 }
 
 struct PatchGeo {
     int TH, TW, tiles_y, tiles_x;
+    int tmb;      // 32-row blocks per wavefront: 1 = 64-pixel blocks, 2 = 128-pixel blocks
+    int diag;     // timing experiments only (MCAV_PATCH_DIAG, wrong results): 1 no filter staging in the loop, 2 no barriers, 4 no patch staging, 8 no MFMAs
 };
 
-constexpr int PATCH_PIX = 108;      // (TH + 2) (TW + 2) <= 108: 4 x 16 -> 108, 8 x 8 -> 100, 6 x 10 -> 96
+template <int TMB>
+struct PatchCfg {                       // TMB 32-row blocks per wavefront: 64- or 128-pixel blocks
+    static constexpr int BM = 64 * TMB;
+    static constexpr int PIX = TMB == 1 ? 108 : 180;      // patch pixels: (TH + 2)(TW + 2) <= PIX: 4 x 16 -> 108 (8 x 8 -> 100, 6 x 10 -> 96); 8 x 16 -> 180
+    static constexpr int NJ = (PIX + 31) / 32;            // patch pixels staged per thread
+    using T = typename std::conditional<TMB == 1, BT64x64k32, BT128x64k32>::type;
+};
 
-template <int NS>
+template <int NS, int TMB>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, const u16* __restrict__ w16, PatchGeo geo) {
-    using T = BT64x64k32;
+    using C = PatchCfg<TMB>;
+    using T = typename C::T;
     // LDS rows are 64 bytes (32 channels: four rows per 256-byte bank row) with the four 16-byte slots of row r XOR-ed by (r >> 2) & 3: a
     // ds_read_b128 lane group (16 lanes: MI355X_MICROARCH.md section LDS) is conflict-free when its 16 rows are distinct mod 16.  The
     // filter rows of a group are (row = lane); for the patch, GEMM row R of the block stands for pixel patch_pixel(R), which gives every
     // lane group 16 consecutive pixels -- one pixel row of a 16-wide block, whose patch rows are consecutive whatever the tap.  The staging
     // stores fill whole 64-byte rows (128 bytes per ds_write group).  (Padded 80-byte rows: half of the LDS cycles were bank conflicts.)
-    constexpr int BM = 64, BN = 64, CKT = 32, LDH = 32;
+    constexpr int BM = C::BM, BN = 64, CKT = 32, LDH = 32, PATCH_PIX = C::PIX;
     constexpr int APL = PATCH_PIX * LDH, BPL = BN * LDH;         // plane strides in elements
-    // dynamic LDS (71 KB in the split form: two workgroups per CU): the patch planes, the filter tiles of ONE FILTER ROW (three taps x planes),
-    // the rows' output offsets.  A stage = one filter row of one chunk: 36 MFMAs per wavefront between two barriers.
+    // dynamic LDS (58 / 72 KB in the split form: two workgroups per CU): the patch planes, the filter tiles of ONE FILTER ROW (three taps x
+    // planes), the rows' output offsets.  A stage = one filter row of one chunk: 36 TMB MFMAs per wavefront between two barriers; the filter
+    // tiles are the kernel's L2 traffic (37 KB per stage), so 128-pixel blocks halve it per FLOP.
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     u16* const Ap = reinterpret_cast<u16*>(s_raw);                                     // [NS][PATCH_PIX][LDH]
     u16* const Bs = Ap + NS * APL;                                                     // [3 taps][NS][BN][LDH]
@@ -434,9 +444,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
     }
     // patch staging: thread -> (patch pixel pp0 + 32 j, 4 channels c4); a pixel outside the image reads as zero (the padding)
     const int c4 = tid & 7, pp0 = tid >> 3;
-    unsigned aoff[4];
+    unsigned aoff[C::NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < C::NJ; ++j) {
         const int pp = pp0 + 32 * j;
         const int ppy = pp / PW, ppx = pp - ppy * PW;
         const int y = ty0 - 1 + ppy, x = tx0 - 1 + ppx;
@@ -451,13 +461,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
     const unsigned boff = (n0 + bn < p.n_count) ? (unsigned)(((p.n_begin + n0 + bn) * p.Kstride + bcb * 8) * 2) : OOB;
 
     const int nchunks = p.Kp / CKT;
-    auto issueA = [&](f32x4 (&ra)[4], int chunk) {
+    auto issueA = [&](f32x4 (&ra)[C::NJ], int chunk) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ra[j] = buf_load4s(rs1, aoff[j], chunk * CKT * 4);
+        for (int j = 0; j < C::NJ; ++j) ra[j] = buf_load4s(rs1, aoff[j], chunk * CKT * 4);
     };
-    auto storeA = [&](const f32x4 (&ra)[4]) {
+    auto storeA = [&](const f32x4 (&ra)[C::NJ]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < C::NJ; ++j) {
             const int pp = pp0 + 32 * j;
             if (pp < PATCH_PIX) {
                 u16* const dst = Ap + pp * LDH + (((c4 >> 1) ^ ((pp >> 2) & 3)) * 8) + (c4 & 1) * 4;
@@ -492,17 +502,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
             for (int q = 0; q < NS; ++q) *reinterpret_cast<f32x4*>(Bs + (kx * NS + q) * BPL + bn * LDH + ((bcb ^ ((bn >> 2) & 3)) * 8)) = rb[kx][q];
     };
 
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-    typename T::AccT acc[1][1], mid, low;
+    const int wm0 = (wave >> 1) * (32 * TMB), wn0 = (wave & 1) * 32;
+    typename T::AccT acc[TMB][1], mid[TMB], low[TMB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; mid[r] = 0.f; low[r] = 0.f; }
+    for (int i = 0; i < TMB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.f; mid[i][r] = 0.f; low[i][r] = 0.f; }
     const int frow = lane & 31;
-    // this lane's A row = output pixel (py, px) of the block -> patch pixel (py + dy, px + dx), dy / dx = the tap (mirrored for the data gradient)
-    int prow;
-    {
-        const int pix = patch_pixel(wm0 + frow);
+    // this lane's A rows = output pixels (py, px) of the block -> patch pixel (py + dy, px + dx), dy / dx = the tap (mirrored for the data gradient)
+    int prow[TMB];
+#pragma unroll
+    for (int i = 0; i < TMB; ++i) {
+        const int pix = patch_pixel(wm0 + 32 * i + frow);
         const int py = pix / TW, px = pix - py * TW;
-        prow = py < TH ? py * PW + px : 0;                       // rows past the block multiply pixel 0 (their results are dropped)
+        prow[i] = py < TH ? py * PW + px : 0;                    // rows past the block multiply pixel 0 (their results are dropped)
     }
     const int fslot = lane >> 5;                                  // which 16-byte half of a k-step this lane holds
     const int brow = wn0 + frow;
@@ -512,18 +525,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
     // A stage's six steps (three taps x two 16-deep k-steps), software-pipelined by hand: the fragments of step i + 1 are read from LDS while
     // the MFMAs of step i run (left to itself the compiler waits for each ds_read right in front of the MFMA that uses it).
     auto compute = [&](int ky) {
-        const int row0 = prow + (fwd ? ky : 2 - ky) * PW + (fwd ? 0 : 2);                  // patch row of tap (ky, 0); tap kx is dxr rows further
+        const int rsh = (fwd ? ky : 2 - ky) * PW + (fwd ? 0 : 2);                          // patch row shift of tap (ky, 0); tap kx is dxr rows further
         const int dxr = fwd ? 1 : -1;
-        bf16x8 fa[2][NS], fb[2][NS];
-        auto load = [&](int i, bf16x8 (&a)[NS], bf16x8 (&b)[NS]) {
+        bf16x8 fa[2][TMB][NS], fb[2][NS];
+        auto load = [&](int i, bf16x8 (&a)[TMB][NS], bf16x8 (&b)[NS]) {
             const int kx = i >> 1, ks = i & 1;
-            const int row = row0 + kx * dxr;
-            const u16* const ap = Ap + row * LDH + (((2 * ks + fslot) ^ ((row >> 2) & 3)) * 8);
             const u16* const bp = (ks ? b_lane1 : b_lane0) + kx * NS * BPL;
 #pragma unroll
-            for (int q = 0; q < NS; ++q) {
-                a[q] = *reinterpret_cast<const bf16x8*>(ap + q * APL);
-                b[q] = *reinterpret_cast<const bf16x8*>(bp + q * BPL);
+            for (int q = 0; q < NS; ++q) b[q] = *reinterpret_cast<const bf16x8*>(bp + q * BPL);
+#pragma unroll
+            for (int t = 0; t < TMB; ++t) {
+                const int row = prow[t] + rsh + kx * dxr;
+                const u16* const ap = Ap + row * LDH + (((2 * ks + fslot) ^ ((row >> 2) & 3)) * 8);
+#pragma unroll
+                for (int q = 0; q < NS; ++q) a[t][q] = *reinterpret_cast<const bf16x8*>(ap + q * APL);
             }
         };
         load(0, fa[0], fb[0]);
@@ -531,70 +546,87 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
         for (int i = 0; i < 6; ++i) {
             if (i + 1 < 6) load(i + 1, fa[(i + 1) & 1], fb[(i + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            const bf16x8(&a)[NS] = fa[i & 1];
             const bf16x8(&b)[NS] = fb[i & 1];
-            if constexpr (NS == 1) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[0][0], 0, 0, 0);
-            } else {
-                low = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], low, 0, 0, 0);
-                mid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], mid, 0, 0, 0);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[0][0], 0, 0, 0);
-                low = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], low, 0, 0, 0);
-                mid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], mid, 0, 0, 0);
-                low = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], low, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TMB; ++t) {
+                const bf16x8(&a)[NS] = fa[i & 1][t];
+                if constexpr (NS == 1) {
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[t][0], 0, 0, 0);
+                } else {
+                    low[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], low[t], 0, 0, 0);
+                    mid[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], mid[t], 0, 0, 0);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[t][0], 0, 0, 0);
+                    low[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], low[t], 0, 0, 0);
+                    mid[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], mid[t], 0, 0, 0);
+                    low[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], low[t], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // The filter tiles are the kernel's traffic (46 KB per stage in the split form against 25 KB of patch per chunk), all of it from L2:
-    // two register stages keep the tiles of stages s + 1 and s + 2 in flight while stage s is multiplied.
-    f32x4 ra[4], rb0[3][NS], rb1[3][NS];
+    // The filter tiles are the kernel's traffic, all of it from L2: the tiles of stage s + 1 (and, in the 64-pixel form, s + 2) are in flight
+    // in registers while stage s is multiplied.
+    constexpr bool TWO = TMB == 1;                               // (the 128-pixel form has no registers for a second filter stage)
+    f32x4 ra[C::NJ], rb0[3][NS], rb1[TWO ? 3 : 1][NS];
     const int total = nchunks * 3;
     issueA(ra, 0);
     issueB(rb0, 0);
     storeA(ra);
     storeB(rb0);
     if (total > 1) issueB(rb0, 1);
-    if (total > 2) issueB(rb1, 2);
+    if constexpr (TWO) {
+        if (total > 2) issueB(rb1, 2);
+    }
     __syncthreads();
     int ky = 0, chunk = 0;
-    auto stage = [&](int s, f32x4 (&rb_next)[3][NS]) {            // rb_next holds stage s + 1 and is re-issued for stage s + 3
+    const int diag = geo.diag;
+    auto stage = [&](int s, auto& rb_next) {                      // rb_next holds stage s + 1 and is re-issued for the stage after those in flight
         const bool more = chunk + 1 < nchunks;
-        if (ky == 0 && more) issueA(ra, chunk + 1);               // lands during the chunk's three stages
-        compute(ky);
-        __syncthreads();
-        if (ky == 2 && more) storeA(ra);
+        if (ky == 0 && more && !(diag & 4)) issueA(ra, chunk + 1);               // lands during the chunk's three stages
+        if (!(diag & 8)) compute(ky);
+        if (!(diag & 2)) __syncthreads();
+        if (ky == 2 && more && !(diag & 4)) storeA(ra);
         if (s + 1 < total) {
-            storeB(rb_next);
-            if (s + 3 < total) issueB(rb_next, s + 3);
-            __syncthreads();
+            if (!(diag & 1)) {
+                storeB(rb_next);
+                if (s + (TWO ? 3 : 2) < total) issueB(rb_next, s + (TWO ? 3 : 2));
+            }
+            if (!(diag & 2)) __syncthreads();
         }
         if (++ky == 3) { ky = 0; ++chunk; }
     };
-    for (int s = 0; s < total; s += 2) {
-        stage(s, rb0);
-        if (s + 1 < total) stage(s + 1, rb1);
+    if constexpr (TWO) {
+        for (int s = 0; s < total; s += 2) {
+            stage(s, rb0);
+            if (s + 1 < total) stage(s + 1, rb1);
+        }
+    } else {
+        for (int s = 0; s < total; ++s) stage(s, rb0);
     }
-    if constexpr (NS > 1) acc[0][0] += mid + low;
+    if constexpr (NS > 1) {
+#pragma unroll
+        for (int t = 0; t < TMB; ++t) acc[t][0] += mid[t] + low[t];
+    }
     igemm_epilogue_lean<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
 }
 
-template <int NS>
-constexpr size_t patch_lds_bytes() { return sizeof(u16) * (size_t)NS * (PATCH_PIX + 3 * 64) * 32 + sizeof(unsigned) * 64; }
+template <int NS, int TMB>
+constexpr size_t patch_lds_bytes() { return sizeof(u16) * (size_t)NS * (PatchCfg<TMB>::PIX + 3 * 64) * 32 + sizeof(unsigned) * 64 * TMB; }
 
-// The block shape for an H x W map: TH TW <= 64 rows, (TH + 2)(TW + 2) <= PATCH_PIX, fewest wasted rows, then the smallest halo.
-static void patch_block(int H, int W, int& TH, int& TW) {
+// The block shape for an H x W map: TH TW <= rows, (TH + 2)(TW + 2) <= pix, fewest wasted rows, then the smallest halo; 16-wide blocks read
+// the patch without bank conflicts (worth some wasted rows).  Returns the cost (rows computed, weighted).
+static double patch_block(int H, int W, int rows, int pix, int& TH, int& TW) {
     double best = 1e30;
-    TH = 8; TW = 8;
-    for (int th = 1; th <= 8; ++th)
+    TH = 4; TW = 16;
+    for (int th = 1; th <= 16; ++th)
         for (int tw = 4; tw <= 64; ++tw) {
-            if (th * tw > 64 || (th + 2) * (tw + 2) > PATCH_PIX) continue;
+            if (th * tw > rows || (th + 2) * (tw + 2) > pix) continue;
             const double tiles = (double)((H + th - 1) / th) * ((W + tw - 1) / tw);
-            // (16-wide blocks read the patch without bank conflicts: worth some wasted rows)
-            const double cost = tiles * 64.0 * (1.0 + 0.05 * (double)((th + 2) * (tw + 2)) / (th * tw)) * (tw == 16 ? 1.0 : 1.25);
+            const double cost = tiles * rows * (1.0 + 0.05 * (double)((th + 2) * (tw + 2)) / (th * tw)) * (tw == 16 ? 1.0 : 1.25);
             if (cost < best) { best = cost; TH = th; TW = tw; }
         }
+    return best;
 }
 
 // 1 = the descriptor runs on conv3x3_patch_kernel (fills geo): a 3x3 stride-1 zero-padded convolution or its data gradient, one source
@@ -606,9 +638,20 @@ static bool patch_plan(const mcav_igemm_desc* d, PatchGeo& geo) {
     if (d->C2 != 0 || d->up1 || d->pool || d->w_upmerge) return false;
     if (d->C1 % 32 != 0 || d->Kp != d->C1 || d->Hd != d->Hs || d->Wd != d->Ws || d->n_count < 32) return false;
     if (d->groups > 1 && d->B % d->groups != 0) return false;
-    patch_block(d->Hd, d->Wd, geo.TH, geo.TW);
+    // 128-pixel blocks (half the filter traffic per FLOP) where they waste no more rows than 64-pixel ones and still fill the chip
+    static const int force_tmb = [] { const char* e = getenv("MCAV_PATCH_TMB"); return e ? atoi(e) : 0; }();
+    int th1, tw1, th2, tw2;
+    const double c1 = patch_block(d->Hd, d->Wd, 64, PatchCfg<1>::PIX, th1, tw1);
+    const double c2 = patch_block(d->Hd, d->Wd, 128, PatchCfg<2>::PIX, th2, tw2);
+    const long wg2 = (long)d->B * ((d->Hd + th2 - 1) / th2) * ((d->Wd + tw2 - 1) / tw2) * ((d->n_count + 63) / 64);
+    geo.tmb = (c2 <= c1 * 1.02 && wg2 >= 1024) ? 2 : 1;
+    if (force_tmb == 1 || force_tmb == 2) geo.tmb = force_tmb;
+    geo.TH = geo.tmb == 2 ? th2 : th1;
+    geo.TW = geo.tmb == 2 ? tw2 : tw1;
     geo.tiles_y = (d->Hd + geo.TH - 1) / geo.TH;
     geo.tiles_x = (d->Wd + geo.TW - 1) / geo.TW;
+    static const int diag = [] { const char* e = getenv("MCAV_PATCH_DIAG"); return e ? atoi(e) : 0; }();
+    geo.diag = diag;
     // plain bf16 on few blocks (the 6x20 maps): the table-driven 32x64 tiles are faster (0.043 against 0.055 ms on 512 -> 512)
     if (d->mma == 1 && (long)d->B * geo.tiles_y * geo.tiles_x * ((d->n_count + 63) / 64) < 1024) return false;
     return true;
@@ -943,14 +986,22 @@ int mcav_bf16_igemm(const mcav_igemm_desc* d, hipStream_t s) {
         p.ntiles = (p.n_count + 63) / 64;
         // (more than 64 KB of dynamic LDS has to be allowed once per kernel)
         static const bool allowed = [] {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)patch_lds_bytes<3>()) == hipSuccess;
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)patch_lds_bytes<3, 2>()) == hipSuccess;
         }();
+        const int grid = p.mtiles * p.ntiles;
+        const u16* w16 = reinterpret_cast<const u16*>(d->w16);
         if (d->mma >= 2) {
-            if (!allowed) return MCAV_E_LAUNCH;
-            timed_launch(conv3x3_patch_kernel<3>, p.mtiles * p.ntiles, dim3(256), patch_lds_bytes<3>(), s, p, reinterpret_cast<const u16*>(d->w16), geo);
+            if (geo.tmb == 2) {
+                if (!allowed) return MCAV_E_LAUNCH;
+                timed_launch(conv3x3_patch_kernel<3, 2>, grid, dim3(256), patch_lds_bytes<3, 2>(), s, p, w16, geo);
+            } else {
+                timed_launch(conv3x3_patch_kernel<3, 1>, grid, dim3(256), patch_lds_bytes<3, 1>(), s, p, w16, geo);
+            }
+        } else if (geo.tmb == 2) {
+            timed_launch(conv3x3_patch_kernel<1, 2>, grid, dim3(256), patch_lds_bytes<1, 2>(), s, p, w16, geo);
         } else {
-            timed_launch(conv3x3_patch_kernel<1>, p.mtiles * p.ntiles, dim3(256), patch_lds_bytes<1>(), s, p, reinterpret_cast<const u16*>(d->w16), geo);
+            timed_launch(conv3x3_patch_kernel<1, 1>, grid, dim3(256), patch_lds_bytes<1, 1>(), s, p, w16, geo);
         }
         return launch_status();
     }
