@@ -367,6 +367,10 @@ def main():
                            "kernel_ms_per_step": round(ms, 3),
                            "by_kind": {k: {"gflop": round(v[0] / 1e9, 2), "ms": round(v[1], 3), "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2),
                                            "launches": v[2] // 3} for k, v in by_kind.items()}}
+        if args.dtype == "fp32-split":
+            out["roofline"]["split_note"] = ("frac = the reference's algorithmic fp32 FLOPs over the fp32 MFMA peak, as for --dtype fp32 (same work, same results to fp32 "
+                                             "rounding); the 3x3 stride-1 zero-padded convolutions and their data gradients run six bf16 MFMA products per fp32 "
+                                             "product on the bf16 pipe (peak %.0f TFLOP/s), every other launch on the fp32 MFMA kernels" % PEAK_BF16_MFMA_TFLOPS)
         rp_ms = rocprof_conv_ms_per_step() if (B, H, W, args.depth_layers, args.dtype, args.ssim) == (12, 192, 640, 18, "fp32", False) else None
         if rp_ms:
             out["roofline"]["frac_rocprof"] = round(flops / (rp_ms * 1e-3) / 1e12 / peak, 4)
