@@ -41,7 +41,7 @@ def _latest(*names):
 TRAFFIC_JSON = _latest("r03_traffic.json", "r02_traffic.json")      # rocprofv3 PMC passes (tools/pmc_summary.py)
 ROCPROF_CSV = _latest("r03_kernel_stats_one_stream.csv", "r02_kernel_stats_one_stream.csv")      # rocprofv3 --kernel-trace --stats of `bench.py --serial`
 CONV_KERNELS = ("igemm_kernel", "igemm_tab_kernel", "igemm_bf16", "wgrad_kernel", "wgrad_tab_kernel", "wgrad_bf16", "conv3x3_halo", "conv3x3r_c1",
-                "stem7x7s2", "splitk_finish", "wgrad_reduce", "wgrad_presum", "patch3x3")
+                "stem7x7s2", "splitk_finish", "wgrad_reduce", "wgrad_presum", "patch3x3", "conv3x3_patch")
 
 
 def rocprof_conv_ms_per_step():

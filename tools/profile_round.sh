@@ -27,4 +27,7 @@ echo ssim pmc done
 rocprofv3 --kernel-trace --stats -d $OUT/stats_bf16 -- python3 $B --steps 10 --warmup 3 --serial --dtype bf16 > $OUT/stats_bf16.log 2>&1
 python3 $ROOT/tools/rocpd_stats.py $(ls $OUT/stats_bf16/*/*_results.db | head -1) $OUT/kernel_stats_serial_bf16.csv
 echo bf16 stats done
-rm -rf $OUT/stats $OUT/stats_serial $OUT/fetch $OUT/write $OUT/fetch_ssim $OUT/write_ssim $OUT/stats_bf16
+rocprofv3 --kernel-trace --stats -d $OUT/stats_split -- python3 $B --steps 10 --warmup 3 --serial --dtype fp32-split > $OUT/stats_split.log 2>&1
+python3 $ROOT/tools/rocpd_stats.py $(ls $OUT/stats_split/*/*_results.db | head -1) $OUT/kernel_stats_serial_split.csv
+echo split stats done
+rm -rf $OUT/stats $OUT/stats_serial $OUT/fetch $OUT/write $OUT/fetch_ssim $OUT/write_ssim $OUT/stats_bf16 $OUT/stats_split
