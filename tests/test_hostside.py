@@ -114,3 +114,24 @@ def test_fused_adam_loads_a_torch_adam_checkpoint():
     for q, f in zip(ref_params, fresh.param_groups[0]["params"]):
         assert torch.equal(fresh.state[f]["exp_avg"], ref.state[q]["exp_avg"])
         assert float(fresh.state[f]["step"]) == 3.0
+
+
+def test_compute_dtype_names_select_the_contraction_form():
+    """mcav.nn.set_compute_dtype: fp32 (default, fp32 MFMA), bf16 (BASELINE.json configs[2] / [4]) and fp32-split (fp32 contractions on the bf16
+    MFMA over split operands, mcav_igemm_desc.mma = 2) mark every convolution of a module; anything else is refused.  Host logic only."""
+    import pytest
+    import torch
+    from mcav import nn as N
+    from mcav.lib import MCAVError
+    from models.depth.resnet_dispnet import DispResNet
+    net = DispResNet(18)
+    convs = [m for m in net.modules() if getattr(m, "weight", None) is not None and m.weight.dim() == 4]
+    assert convs and all(getattr(m, "_mcav_mma", N.MMA_FP32) == N.MMA_FP32 for m in convs)
+    for name, want in (("bf16", N.MMA_BF16), (torch.bfloat16, N.MMA_BF16), ("fp32-split", N.MMA_SPLIT), ("f32s", N.MMA_SPLIT),
+                       ("fp32", N.MMA_FP32), (torch.float32, N.MMA_FP32)):
+        N.set_compute_dtype(net, name)
+        assert all(m._mcav_mma == want for m in convs), name
+    with pytest.raises(MCAVError):
+        N.set_compute_dtype(net, "fp16")
+    assert DispResNet(18, dtype="fp32-split").encoder.encoder.conv1._mcav_mma == N.MMA_SPLIT
+    assert (N.MMA_FP32, N.MMA_BF16, N.MMA_SPLIT, N.MMA_SPLIT_ALL) == (0, 1, 2, 3)        # the values of mcav_igemm_desc.mma (include/mcav_conv.h)
