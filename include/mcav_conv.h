@@ -63,7 +63,8 @@ typedef struct mcav_igemm_desc {
     const float* addend;    /* same layout as y */
     int pool;               /* 1: destination pixels are visited in 2x2 blocks and summed: y is [B, Hd/2, Wd/2, Cd] */
     float* stats;           /* NULL or [mtiles][2][n_count]: per-tile column sums of y and y^2 (BatchNorm batch statistics) */
-    int tile;               /* 0 = choose automatically; else a tile-config id */
+    int tile;               /* 0 = choose automatically; else a tile-config id in the low byte; bits 8-13 = test / tuning switches that force or forbid one
+                             * of the kernel forms (bit 13: the fp32 patch-in-LDS kernel for 3x3 stride-1 zero-padded launches) */
     int groups;             /* 0/1 = one group.  G > 1: the batch is G equal groups (e.g. the tgt and ref0 passes of the depth net run as
                              * one launch); output tiles never straddle a group, so `stats` rows [g * mtiles/G, (g+1) * mtiles/G) belong to
                              * group g (per-pass BatchNorm statistics).  Only with the DIRECT / SMALLC gathers and pool == 0. */

@@ -484,3 +484,39 @@ def test_kernel_timer_counts_conv_dispatches():
     assert torch.equal(y0, y1) and torch.equal(y0, y2)
     N.conv_fwd(spec, xd)
     assert N.L.lib().mcav_kernel_timer_count() == 0
+
+
+@pytest.mark.parametrize("case", [(2, 12, 20, 64, 64), (2, 24, 48, 64, 128), (3, 6, 20, 128, 96), (2, 8, 16, 32, 64)])
+def test_fp32_patch_in_lds_kernel_matches_the_table_driven_one(case):
+    """conv3x3_patch_f32_kernel (csrc/conv_bf16.hip; opt-in: MCAV_PATCH_F32=1 or bit 13 of the descriptor's tile word): the 3x3 stride-1
+    zero-padded convolution and its data gradient from a source patch kept in LDS, fp32 MFMA -- forward with bias + ReLU and with the
+    BatchNorm statistics epilogue (two groups), data gradient with the ReLU-derivative factor and an addend, against float64 and against the
+    table-driven kernel (reference seam: torchvision BasicBlock conv1 / conv2, resnet_dispnet.py:38-44)."""
+    from mcav import nn as N
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = 0.1 * torch.randn(Cout, generator=g)
+    spec = N.ConvSpec(torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV)), 1, 1, N.PAD_ZERO)
+    PATCH = 1 << 13
+    want = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    got = N.conv_fwd(spec, nhwc(x), act=N.ACT_RELU, tile=PATCH)
+    ref = N.conv_fwd(spec, nhwc(x), act=N.ACT_RELU)
+    assert rel_err(nchw(got), want) < 2e-6 and rel_err(nchw(got), nchw(ref)) < 2e-6
+    nob = N.ConvSpec(spec.weight, None, 1, 1, N.PAD_ZERO)
+    G = 2 if B % 2 == 0 else 1
+    y, slab = N.conv_fwd(nob, nhwc(x), stats=True, groups=G, tile=PATCH)
+    raw = F.conv2d(x.double(), w.double(), None, padding=1)
+    assert rel_err(nchw(y), raw) < 2e-6
+    mt = slab.shape[0] // G
+    for grp in range(G):
+        part = raw[grp * (B // G):(grp + 1) * (B // G)]
+        s = slab[grp * mt:(grp + 1) * mt].double().sum(0).cpu()
+        assert rel_err(s[0], part.sum((0, 2, 3))) < 2e-5 and rel_err(s[1], (part ** 2).sum((0, 2, 3))) < 2e-6
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    aux = torch.randn(B, Cin, H, W, generator=g)
+    add = torch.randn(B, Cin, H, W, generator=g)
+    dxw = F.conv_transpose2d(dy.double(), w.double(), padding=1) * (aux.double() > 0) + add.double()
+    dx = N.conv_dgrad(spec, nhwc(dy), (H, W), dact_aux=nhwc(aux), dact=N.ACT_RELU, addend=nhwc(add), tile=PATCH)
+    assert rel_err(nchw(dx), dxw) < 2e-6

@@ -614,6 +614,168 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
 template <int NS, int TMB>
 constexpr size_t patch_lds_bytes() { return sizeof(u16) * (size_t)NS * (PatchCfg<TMB>::PIX + 3 * 64) * 32 + sizeof(unsigned) * 64 * TMB; }
 
+// ------------------------------------------------------------------------------------------------ the same on the fp32 MFMA (mma = 0)
+// conv3x3_patch_kernel's structure with fp32 operands and v_mfma_f32_32x32x2_f32: the default (fp32) path of the trunk's 3x3 stride-1
+// zero-padded convolutions and their data gradients.  The table-driven kernel fetches the A operand once per tap through L2; with those
+// fetches redirected to a few hot lines it ran 8-10 % faster (22 % on the 6x20 maps) -- here the patch of a
+// 32-channel chunk is fetched once.  LDS: 128-byte rows (32 floats), the eight 16-byte slots of row r XOR-ed by (r >> 1) & 7 (a
+// ds_read_b128 lane group of 16 rows distinct mod 16 covers all sixteen slots of the 256-byte bank row); a fragment read = four consecutive
+// channels = the operands of four MFMAs (lane half h holds channels 8 g + 4 h + e of group g, e = the MFMA).  A stage = one filter row of a
+// chunk: 48 TMB MFMAs (3072 TMB cycles) per wavefront between two barriers; 39 / 48 KB of LDS.
+template <int TMB>
+__global__ __launch_bounds__(256, TMB == 1 ? 4 : 3) void conv3x3_patch_f32_kernel(IgemmParams p, PatchGeo geo) {
+    using C = PatchCfg<TMB>;
+    using T = typename C::T;
+    constexpr int BM = C::BM, BN = 64, CKT = 32, LDF = 32, PATCH_PIX = C::PIX;
+    constexpr int BPL = BN * LDF;                                 // one tap's filter tile in floats
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    float* const Ap = reinterpret_cast<float*>(s_raw);                                  // [PATCH_PIX][LDF]
+    float* const Bs = Ap + PATCH_PIX * LDF;                                             // [3 taps][BN][LDF]
+    unsigned* const s_out = reinterpret_cast<unsigned*>(Bs + 3 * BPL);                 // [BM]
+    float (*const s_stat)[2][BN] = reinterpret_cast<float (*)[2][BN]>(Bs);
+    static_assert(sizeof(float) * BPL >= sizeof(float) * T::WAVES_M * 2 * BN, "statistics scratch fits a filter tile");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = lid % p.ntiles, mt = lid / p.ntiles;
+    const int n0 = nt * BN;
+    const GatherSrc& g = p.g;
+    const int TH = geo.TH, TW = geo.TW, PW = TW + 2, PH = TH + 2;
+    const int per_img = geo.tiles_y * geo.tiles_x;
+    const int img = mt / per_img, tr = mt - img * per_img;
+    const int ty0 = (tr / geo.tiles_x) * TH, tx0 = (tr % geo.tiles_x) * TW;
+    if (tid < BM) {
+        const int pix = patch_pixel(tid);
+        const int py = pix / TW, px = pix - py * TW;
+        const int y = ty0 + py, x = tx0 + px;
+        s_out[tid] = (py < TH && y < p.Hd && x < p.Wd) ? (unsigned)((img * p.Hd + y) * p.Wd + x) * (unsigned)(p.Cd * 4) : OOB;
+    }
+    // patch staging: thread -> (patch pixel pp0 + 32 j, 4 channels c4)
+    const int c4 = tid & 7, pp0 = tid >> 3;
+    unsigned aoff[C::NJ];
+#pragma unroll
+    for (int j = 0; j < C::NJ; ++j) {
+        const int pp = pp0 + 32 * j;
+        const int ppy = pp / PW, ppx = pp - ppy * PW;
+        const int y = ty0 - 1 + ppy, x = tx0 - 1 + ppx;
+        const bool ok = pp < PH * PW && (unsigned)y < (unsigned)g.Hs && (unsigned)x < (unsigned)g.Ws;
+        aoff[j] = ok ? (unsigned)((((img * g.Hs + y) * g.Ws + x) * g.C1 + c4 * 4) * 4) : OOB;
+    }
+    const unsigned bytes1 = (unsigned)((size_t)g.B * g.Hs * g.Ws * g.C1 * 4);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1, bytes1);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, (unsigned)((size_t)(p.n_begin + p.n_count) * p.Kstride * 4));
+    // filter tile of a tap: 64 rows x 8 slots of 16 bytes; thread -> pieces tid and tid + 256
+    const int bn0 = tid >> 3, bsl = tid & 7;                      // rows bn0 and bn0 + 32, slot bsl
+    unsigned boff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int bn = bn0 + 32 * h;
+        boff[h] = (n0 + bn < p.n_count) ? (unsigned)(((p.n_begin + n0 + bn) * p.Kstride + bsl * 4) * 4) : OOB;
+    }
+    const int nchunks = p.Kp / CKT;
+    auto issueA = [&](f32x4 (&ra)[C::NJ], int chunk) {
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) ra[j] = buf_load4s(rs1, aoff[j], chunk * CKT * 4);
+    };
+    auto storeA = [&](const f32x4 (&ra)[C::NJ]) {
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) {
+            const int pp = pp0 + 32 * j;
+            if (pp < PATCH_PIX) *reinterpret_cast<f32x4*>(Ap + pp * LDF + ((c4 ^ ((pp >> 1) & 7)) * 4)) = ra[j];
+        }
+    };
+    auto issueB = [&](f32x4 (&rb)[3][2], int s) {
+        const int chunk = s / 3, ky = s - chunk * 3;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int kb = ((ky * 3 + kx) * p.Kp + chunk * CKT) * 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) rb[kx][h] = buf_load4s(rsw, boff[h], kb);
+        }
+    };
+    auto storeB = [&](const f32x4 (&rb)[3][2]) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int bn = bn0 + 32 * h;
+                *reinterpret_cast<f32x4*>(Bs + kx * BPL + bn * LDF + ((bsl ^ ((bn >> 1) & 7)) * 4)) = rb[kx][h];
+            }
+    };
+
+    const int wm0 = (wave >> 1) * (32 * TMB), wn0 = (wave & 1) * 32;
+    typename T::AccT acc[TMB][1];
+#pragma unroll
+    for (int i = 0; i < TMB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    const int frow = lane & 31, fh = lane >> 5;
+    int prow[TMB];
+#pragma unroll
+    for (int i = 0; i < TMB; ++i) {
+        const int pix = patch_pixel(wm0 + 32 * i + frow);
+        const int py = pix / TW, px = pix - py * TW;
+        prow[i] = py < TH ? py * PW + px : 0;
+    }
+    const int brow = wn0 + frow;
+    const bool fwd = g.sign > 0;
+    // twelve steps per stage (three taps x four 8-channel groups); the fragments of step i + 1 are read while the four MFMAs of step i run
+    auto compute = [&](int ky) {
+        const int rsh = (fwd ? ky : 2 - ky) * PW + (fwd ? 0 : 2);
+        const int dxr = fwd ? 1 : -1;
+        f32x4 fa[2][TMB], fb[2];
+        auto load = [&](int i, f32x4 (&a)[TMB], f32x4& b) {
+            const int kx = i >> 2, kg = i & 3;
+            const int slot = 2 * kg + fh;
+            b = *reinterpret_cast<const f32x4*>(Bs + kx * BPL + brow * LDF + ((slot ^ ((brow >> 1) & 7)) * 4));
+#pragma unroll
+            for (int t = 0; t < TMB; ++t) {
+                const int row = prow[t] + rsh + kx * dxr;
+                a[t] = *reinterpret_cast<const f32x4*>(Ap + row * LDF + ((slot ^ ((row >> 1) & 7)) * 4));
+            }
+        };
+        load(0, fa[0], fb[0]);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            if (i + 1 < 12) load(i + 1, fa[(i + 1) & 1], fb[(i + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < TMB; ++t)
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i & 1][t][e], fb[i & 1][e], acc[t][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    f32x4 ra[C::NJ], rb[3][2];
+    const int total = nchunks * 3;
+    issueA(ra, 0);
+    issueB(rb, 0);
+    storeA(ra);
+    storeB(rb);
+    if (total > 1) issueB(rb, 1);
+    __syncthreads();
+    int ky = 0, chunk = 0;
+    for (int s = 0; s < total; ++s) {
+        const bool more = chunk + 1 < nchunks;
+        if (ky == 0 && more) issueA(ra, chunk + 1);               // lands during the chunk's three stages
+        compute(ky);
+        __syncthreads();
+        if (ky == 2 && more) storeA(ra);
+        if (s + 1 < total) {
+            storeB(rb);
+            if (s + 2 < total) issueB(rb, s + 2);
+            __syncthreads();
+        }
+        if (++ky == 3) { ky = 0; ++chunk; }
+    }
+    igemm_epilogue_lean<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
+}
+
+template <int TMB>
+constexpr size_t patch_f32_lds_bytes() { return sizeof(float) * (size_t)(PatchCfg<TMB>::PIX + 3 * 64) * 32 + sizeof(unsigned) * 64 * TMB; }
+
 // The block shape for an H x W map: TH TW <= rows, (TH + 2)(TW + 2) <= pix, fewest wasted rows, then the smallest halo; 16-wide blocks read
 // the patch without bank conflicts (worth some wasted rows).  Returns the cost (rows computed, weighted).
 static double patch_block(int H, int W, int rows, int pix, int& TH, int& TW) {
@@ -630,9 +792,10 @@ static double patch_block(int H, int W, int rows, int pix, int& TH, int& TW) {
 }
 
 // 1 = the descriptor runs on conv3x3_patch_kernel (fills geo): a 3x3 stride-1 zero-padded convolution or its data gradient, one source
-static bool patch_plan(const mcav_igemm_desc* d, PatchGeo& geo) {
+static bool patch_plan(const mcav_igemm_desc* d, PatchGeo& geo, bool f32 = false) {
     static const int enabled = [] { const char* e = getenv("MCAV_PATCH"); return e ? atoi(e) : 1; }();
-    if (!enabled || !d || !d->w16 || (d->mma < 1 || d->mma > 3)) return false;
+    if (!enabled || !d) return false;
+    if (f32 ? (d->mma != 0 || !d->w) : (!d->w16 || d->mma < 1 || d->mma > 3)) return false;
     if (d->mode != MCAV_G_DIRECT || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_mode != MCAV_PAD_ZERO) return false;
     if (!((d->sign == 1 && d->offset == -1) || (d->sign == -1 && d->offset == 1))) return false;
     if (d->C2 != 0 || d->up1 || d->pool || d->w_upmerge) return false;
@@ -965,6 +1128,37 @@ static int bf16_tile_for(const mcav_igemm_desc* d, bool* refl) {
 }  // namespace mcav
 
 using namespace mcav;
+
+// fp32 MFMA patch kernel (mma = 0): which descriptors take it.  Measured level with the table-driven kernels on the 48x160 / 24x80 maps
+// (0.129 against 0.133 ms, 0.115 against 0.112) and behind them on the 12x40 / 6x20 maps (ragged 16-wide blocks), so it is OFF by default:
+// MCAV_PATCH_F32=1, or bit 13 of mcav_igemm_desc.tile (the parity test), selects it.
+static bool patch_f32_plan(const mcav_igemm_desc* d, PatchGeo& geo) {
+    static const int enabled = [] { const char* e = getenv("MCAV_PATCH_F32"); return e ? atoi(e) : 0; }();
+    if (!d || (!enabled && !((d->tile >> 13) & 1))) return false;
+    return patch_plan(d, geo, true);
+}
+
+int mcav_patch_f32_mtiles(const mcav_igemm_desc* d) {
+    PatchGeo geo;
+    return patch_f32_plan(d, geo) ? d->B * geo.tiles_y * geo.tiles_x : 0;
+}
+
+bool mcav_try_patch_f32(const mcav_igemm_desc* d, hipStream_t s) {
+    PatchGeo geo;
+    if (!patch_f32_plan(d, geo)) return false;
+    mcav_igemm_desc dd = *d;
+    dd.tile = 2;
+    dd.w_upmerge = nullptr;
+    IgemmParams p;
+    int tile;
+    if (!fill_params(&dd, p, tile) || p.upm) return false;
+    p.mtiles = d->B * geo.tiles_y * geo.tiles_x;
+    p.ntiles = (p.n_count + 63) / 64;
+    const int grid = p.mtiles * p.ntiles;
+    if (geo.tmb == 2) timed_launch(conv3x3_patch_f32_kernel<2>, grid, dim3(256), patch_f32_lds_bytes<2>(), s, p, geo);
+    else timed_launch(conv3x3_patch_f32_kernel<1>, grid, dim3(256), patch_f32_lds_bytes<1>(), s, p, geo);
+    return true;
+}
 
 // returns 1 when the launch is not eligible (run the fp32 path), MCAV_OK / MCAV_E_* otherwise
 int mcav_bf16_igemm(const mcav_igemm_desc* d, hipStream_t s) {

@@ -1908,6 +1908,8 @@ inline void launch_igemm(const IgemmParams& p_in, hipStream_t s) {
 using namespace mcav;
 
 int mcav_bf16_igemm_mtiles(const mcav_igemm_desc* d);             // conv_bf16.hip: 0 = the launch does not run there
+int mcav_patch_f32_mtiles(const mcav_igemm_desc* d);              // conv_bf16.hip: blocks of the fp32 patch-in-LDS kernel, 0 = not one of its launches
+bool mcav_try_patch_f32(const mcav_igemm_desc* d, hipStream_t s);
 int mcav_stem_mtiles(const mcav_igemm_desc* d);                   // conv_stem.hip: 0 = not the image stem
 
 MCAV_EXPORT int mcav_igemm_mtiles(const mcav_igemm_desc* d) {
@@ -1915,6 +1917,7 @@ MCAV_EXPORT int mcav_igemm_mtiles(const mcav_igemm_desc* d) {
     int tile;
     if (!fill_params(d, p, tile)) return MCAV_E_INVALID;
     if (const int st = mcav_stem_mtiles(d)) return st;             // the stem kernel's 8 x 32 output tiles
+    if (const int pt = mcav_patch_f32_mtiles(d)) return pt;         // the fp32 patch-in-LDS kernel's blocks (conv_bf16.hip)
     if (d->mma != 0) {                              // the bf16 kernels choose their own tile shape
         const int mt = mcav_bf16_igemm_mtiles(d);
         if (mt > 0) return mt;
@@ -1936,6 +1939,7 @@ MCAV_EXPORT int mcav_igemm(const mcav_igemm_desc* d, void* stream) {
     hipStream_t s = as_stream(stream);
     if (mcav_try_halo(d, s)) return launch_status();
     if (mcav_try_stem(d, p, s)) return launch_status();
+    if (mcav_try_patch_f32(d, s)) return launch_status();
     if (d->mma != 0) {                    // bf16 MFMA tiles (conv_bf16.hip) where the launch qualifies, else the fp32 kernels below
         const int rc = mcav_bf16_igemm(d, s);
         if (rc != 1) return rc;
