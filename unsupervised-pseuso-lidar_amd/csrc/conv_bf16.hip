@@ -400,7 +400,7 @@ struct PatchGeo {
 template <int TMB>
 struct PatchCfg {                       // TMB 32-row blocks per wavefront: 64- or 128-pixel blocks
     static constexpr int BM = 64 * TMB;
-    static constexpr int PIX = TMB == 1 ? 108 : 180;      // patch pixels: (TH + 2)(TW + 2) <= PIX: 4 x 16 -> 108 (8 x 8 -> 100, 6 x 10 -> 96); 8 x 16 -> 180
+    static constexpr int PIX = TMB == 1 ? 110 : 180;      // patch pixels: (TH + 2)(TW + 2) <= PIX: 4 x 16 -> 108, 3 x 20 -> 110 (8 x 8 -> 100, 6 x 10 -> 96); 8 x 16 -> 180, 6 x 20 -> 176
     static constexpr int NJ = (PIX + 31) / 32;            // patch pixels staged per thread
     using T = typename std::conditional<TMB == 1, BT64x64k32, BT128x64k32>::type;
 };
@@ -785,7 +785,10 @@ static double patch_block(int H, int W, int rows, int pix, int& TH, int& TW) {
         for (int tw = 4; tw <= 64; ++tw) {
             if (th * tw > rows || (th + 2) * (tw + 2) > pix) continue;
             const double tiles = (double)((H + th - 1) / th) * ((W + tw - 1) / tw);
-            const double cost = tiles * rows * (1.0 + 0.05 * (double)((th + 2) * (tw + 2)) / (th * tw)) * (tw == 16 ? 1.0 : 1.25);
+            // a lane group = 16 consecutive pixels of the block: one pixel row of a 16-wide block (conflict-free); of a wider block with
+            // tw % 4 == 0 at most two runs of a row each (two lanes collide); anything else scatters
+            const double bank = tw % 16 == 0 ? 1.0 : (tw > 16 && tw % 4 == 0 ? 1.05 : 1.25);
+            const double cost = tiles * rows * (1.0 + 0.05 * (double)((th + 2) * (tw + 2)) / (th * tw)) * bank;
             if (cost < best) { best = cost; TH = th; TW = tw; }
         }
     return best;
