@@ -8,6 +8,8 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// LDS = 2: as 1, with a workgroup barrier every three iterations (36 MFMAs: the stage of conv3x3_patch_kernel) and the first fragments of
+// the next stage read only after it -- what a stage boundary costs a wavefront that has no partner on its SIMD.
 template <int LDS>
 __global__ __launch_bounds__(256) void loop(float* out, int iters) {
     __shared__ __attribute__((aligned(16))) unsigned short panel[6][64][40];
@@ -22,6 +24,11 @@ __global__ __launch_bounds__(256) void loop(float* out, int iters) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) f[1][q] = f[0][q];
     for (int it = 0; it < iters; ++it) {
+        if (LDS == 2 && it % 3 == 0) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 6; ++q) f[0][q] = *reinterpret_cast<const bf16x8*>(base + q * 64 * 40 + (it & 1) * 16);
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             if (LDS) {
@@ -64,7 +71,7 @@ static void run(int waves_per_simd, int iters) {
         const double mfmas = (double)blocks * 4 * iters * 12;
         const double tf = mfmas * 32768.0 / (ms * 1e-3) / 1e12;
         if (rep == 2)
-            printf("%-28s %d wavefront(s) per SIMD: %8.3f ms  %8.1f TFLOP/s  %6.1f cycles per MFMA per SIMD at 2.4 GHz\n", LDS ? "operands re-read from LDS" : "operands in registers",
+            printf("%-28s %d wavefront(s) per SIMD: %8.3f ms  %8.1f TFLOP/s  %6.1f cycles per MFMA per SIMD at 2.4 GHz\n", LDS == 2 ? "LDS + barrier per 36 MFMAs" : LDS ? "operands re-read from LDS" : "operands in registers",
                    waves_per_simd, ms, tf, ms * 1e-3 * 2.4e9 / ((double)waves_per_simd * iters * 12));
     }
     hipFree(out);
@@ -73,5 +80,6 @@ static void run(int waves_per_simd, int iters) {
 int main() {
     for (int w : {1, 2, 4}) run<0>(w, 20000 / w);
     for (int w : {1, 2, 4}) run<1>(w, 20000 / w);
+    for (int w : {1, 2, 4}) run<2>(w, 19998 / w / 3 * 3);
     return 0;
 }
