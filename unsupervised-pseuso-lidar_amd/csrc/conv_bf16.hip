@@ -394,7 +394,7 @@ __device__ __forceinline__ int patch_pixel(int R) {
 struct PatchGeo {
     int TH, TW, tiles_y, tiles_x;
     int tmb;      // 32-row blocks per wavefront: 1 = 64-pixel blocks, 2 = 128-pixel blocks
-    int diag;     // timing experiments only (MCAV_PATCH_DIAG, wrong results): 1 no filter staging in the loop, 2 no barriers, 4 no patch staging, 8 no MFMAs
+    int diag;     // timing experiments only (MCAV_PATCH_DIAG, wrong results): 1 no filter staging in the loop, 2 no barriers, 4 no patch staging, 8 no MFMAs, 16 no epilogue
 };
 
 template <int TMB>
@@ -608,6 +608,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
 #pragma unroll
         for (int t = 0; t < TMB; ++t) acc[t][0] += mid[t] + low[t];
     }
+    if (diag & 16) return;                                        // (timing only: no epilogue)
     igemm_epilogue_lean<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
 }
 
