@@ -137,3 +137,23 @@ def test_config4_bf16_two_resolution_step_graphs_equal_eager():
     assert losses == ref_losses, (losses, ref_losses)
     assert_same_state(got, ref_state, True, "configs[4]: two-resolution bf16 graphs vs eager")
     assert losses[0] != losses[2] and losses[0] != losses[1]                  # different batches, updated weights
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_step_graphs_small_then_large_in_a_fresh_process(mode):
+    """a graph captured for a small shape keeps the addresses of the cached weight-gradient slab buffers and of the
+    batched reduction's device table; a larger shape arriving later must not free them.  A child process (nothing pre-sized by an eager run)
+    builds StepGraphs on 2x64x128 first, then 12x192x640, and replays A, B, A, B: bit-equal to the same four steps issued eagerly, and the
+    scenario is real -- the larger shape did outgrow slab buffers of the first capture (they are retired, not freed: mcav/nn.py _WgradBatch)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "graph_fresh_worker.py"), mode], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "worker rc %d\nstdout: %s\nstderr: %s" % (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    print(out)
+    assert out["slab_buffers_retired"] > 0, "the larger shape outgrew no slab buffer: the test does not exercise the hazard"
+    assert out["losses"] == out["ref_losses"], out
+    assert out["state_equal"] and out["buffers_equal"], out

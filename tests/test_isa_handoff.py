@@ -1,0 +1,78 @@
+"""CPU: the cross-workgroup hand-off of the fused loss kernels, checked in the compiled gfx950 ISA.
+
+csrc/mcav_common.h states the protocol ("every workgroup leaves a partial result, the last one to draw a ticket finishes"): published words
+are stored at agent scope (sc1), EVERY thread waits for its stores to be acknowledged (s_waitcnt vmcnt(0)) before the workgroup's ticket --
+an agent-scope atomic add -- is taken, and the finisher reads with sc1 loads.  The HIP memory model only promises this for agent-scope
+release / acquire fences, which on this chip cost an L2 write-back + invalidate per workgroup; the cheap form relies on what the compiler
+emits, so this test compiles csrc/warp_loss.hip for the device (hipcc cross-compiles without a GPU, ~10 s) and reads the assembly: a
+compiler or ROCm upgrade that drops the sc1 bit or moves the wait is caught here, not as silently wrong losses on the GPU.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(REPO, "unsupervised-pseuso-lidar_amd", "csrc", "warp_loss.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if not os.path.exists(HIPCC) and shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    out = str(tmp_path_factory.mktemp("isa") / "warp_loss.s")
+    subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+                           "-o", out, SRC], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    # split into functions: "<name>:" at column 0 up to its ".Lfunc_end"
+    funcs = {}
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", text, re.S | re.M):
+        body = [l.strip() for l in m.group(2).splitlines()]
+        funcs[m.group(1)] = [l for l in body if l and not l.startswith((";", ".", "//")) or l.startswith(".LBB")]
+    return funcs
+
+
+def _ticket_kernels(funcs):
+    return {n: b for n, b in funcs.items() if any(i.startswith("global_atomic_add") for i in b)}
+
+
+def test_loss_kernels_take_tickets(kernels):
+    tk = _ticket_kernels(kernels)
+    names = " ".join(tk)
+    assert "warp_loss_l1_kernel" in names and "warp_loss_ssim_kernel" in names, names
+
+
+def test_stores_are_acknowledged_before_every_ticket(kernels):
+    """Walking back from each ticket atomic, an `s_waitcnt vmcnt(0)` comes before any global store (barriers and ALU work may sit between)."""
+    for name, body in _ticket_kernels(kernels).items():
+        for i, ins in enumerate(body):
+            if not ins.startswith("global_atomic_add"):
+                continue
+            assert " sc0" in ins, (name, ins)                     # returns the pre-op value: the ticket
+            for j in range(i - 1, -1, -1):
+                prev = body[j]
+                if prev.startswith("s_waitcnt") and "vmcnt(0)" in prev:
+                    break
+                assert not prev.startswith(("global_store", "buffer_store", "flat_store")), \
+                    "%s: a global store is issued between the last s_waitcnt vmcnt(0) and the ticket at instruction %d: %s" % (name, i, prev)
+            else:
+                raise AssertionError("%s: no s_waitcnt vmcnt(0) in front of the ticket at instruction %d" % (name, i))
+
+
+def test_published_words_and_finisher_reads_are_agent_scope(kernels):
+    """After the first ticket of a kernel only the finisher runs: every store it issues to global memory that other workgroups / the next
+    launch's finisher read (sample sums, ticket resets) is sc1, and it reads the slab and the sample sums with sc1 loads.  In front of the
+    ticket the workgroup's slab entry is stored sc1."""
+    for name, body in _ticket_kernels(kernels).items():
+        first = next(i for i, ins in enumerate(body) if ins.startswith("global_atomic_add"))
+        before, after = body[:first], body[first:]
+        sc1_before = [i for i in before if i.startswith("global_store") and " sc1" in i]
+        assert sc1_before, "%s: no agent-scope slab store in front of the ticket" % name
+        sc1_loads = [i for i in after if i.startswith("global_load") and " sc1" in i]
+        assert len(sc1_loads) >= 2, "%s: the finisher's slab / sample-sum loads are not agent-scope: %s" % (name, sc1_loads)
+        sc1_after = [i for i in after if i.startswith("global_store") and " sc1" in i]
+        assert len(sc1_after) >= 3, "%s: sample sums / ticket resets are not agent-scope stores: %s" % (name, sc1_after)
+        assert not any(i.startswith(("buffer_wbl2", "buffer_inv")) for i in body), "%s: an L2 write-back / invalidate crept in" % name

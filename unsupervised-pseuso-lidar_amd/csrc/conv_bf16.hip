@@ -394,8 +394,14 @@ __device__ __forceinline__ int patch_pixel(int R) {
 struct PatchGeo {
     int TH, TW, tiles_y, tiles_x;
     int tmb;      // 32-row blocks per wavefront: 1 = 64-pixel blocks, 2 = 128-pixel blocks
-    int diag;     // timing experiments only (MCAV_PATCH_DIAG, wrong results): 1 no filter staging in the loop, 2 no barriers, 4 no patch staging, 8 no MFMAs, 16 no epilogue
 };
+
+// Timing experiments only, WRONG results: a compile-time value of experiment builds (make variant NAME=pd8 FLAGS=-DMCAV_PATCH_DIAG=8), zero
+// -- every branch on it folded away -- in the shipped library.  1 no filter staging in the loop, 2 no barriers, 4 no patch staging, 8 no
+// MFMAs, 16 no epilogue.
+#ifndef MCAV_PATCH_DIAG
+#define MCAV_PATCH_DIAG 0
+#endif
 
 template <int TMB>
 struct PatchCfg {                       // TMB 32-row blocks per wavefront: 64- or 128-pixel blocks
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
     }
     __syncthreads();
     int ky = 0, chunk = 0;
-    const int diag = geo.diag;
+    constexpr int diag = MCAV_PATCH_DIAG;
     auto stage = [&](int s, auto& rb_next) {                      // rb_next holds stage s + 1 and is re-issued for the stage after those in flight
         const bool more = chunk + 1 < nchunks;
         if (ky == 0 && more && !(diag & 4)) issueA(ra, chunk + 1);               // lands during the chunk's three stages
@@ -797,7 +803,7 @@ static double patch_block(int H, int W, int rows, int pix, int& TH, int& TW) {
 
 // 1 = the descriptor runs on conv3x3_patch_kernel (fills geo): a 3x3 stride-1 zero-padded convolution or its data gradient, one source
 static bool patch_plan(const mcav_igemm_desc* d, PatchGeo& geo, bool f32 = false) {
-    static const int enabled = [] { const char* e = getenv("MCAV_PATCH"); return e ? atoi(e) : 1; }();
+    static const int enabled = MCAV_KNOB_INT("MCAV_PATCH", 1);
     if (!enabled || !d) return false;
     if (f32 ? (d->mma != 0 || !d->w) : (!d->w16 || d->mma < 1 || d->mma > 3)) return false;
     if (d->mode != MCAV_G_DIRECT || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_mode != MCAV_PAD_ZERO) return false;
@@ -806,7 +812,7 @@ static bool patch_plan(const mcav_igemm_desc* d, PatchGeo& geo, bool f32 = false
     if (d->C1 % 32 != 0 || d->Kp != d->C1 || d->Hd != d->Hs || d->Wd != d->Ws || d->n_count < 32) return false;
     if (d->groups > 1 && d->B % d->groups != 0) return false;
     // 128-pixel blocks (half the filter traffic per FLOP) where they waste no more rows than 64-pixel ones and still fill the chip
-    static const int force_tmb = [] { const char* e = getenv("MCAV_PATCH_TMB"); return e ? atoi(e) : 0; }();
+    static const int force_tmb = MCAV_KNOB_INT("MCAV_PATCH_TMB", 0);
     int th1, tw1, th2, tw2;
     const double c1 = patch_block(d->Hd, d->Wd, 64, PatchCfg<1>::PIX, th1, tw1);
     const double c2 = patch_block(d->Hd, d->Wd, 128, PatchCfg<2>::PIX, th2, tw2);
@@ -817,8 +823,6 @@ static bool patch_plan(const mcav_igemm_desc* d, PatchGeo& geo, bool f32 = false
     geo.TW = geo.tmb == 2 ? tw2 : tw1;
     geo.tiles_y = (d->Hd + geo.TH - 1) / geo.TH;
     geo.tiles_x = (d->Wd + geo.TW - 1) / geo.TW;
-    static const int diag = [] { const char* e = getenv("MCAV_PATCH_DIAG"); return e ? atoi(e) : 0; }();
-    geo.diag = diag;
     // plain bf16 on few blocks (the 6x20 maps): the table-driven 32x64 tiles are faster (0.043 against 0.055 ms on 512 -> 512)
     if (d->mma == 1 && (long)d->B * geo.tiles_y * geo.tiles_x * ((d->n_count + 63) / 64) < 1024) return false;
     return true;
@@ -1123,7 +1127,7 @@ static int bf16_tile_for(const mcav_igemm_desc* d, bool* refl) {
     if (wg64 >= 4096 && !radj) shape = 8;                             // many rows: 128 x 64 (half the filter re-reads)
     else if (wg64 < 512) shape = 12;                                  // few rows (6x20 maps): 32 x 64
     if (d->mma >= 2) {
-        static const int forced = [] { const char* e = getenv("MCAV_SPLIT_TILE"); return e ? atoi(e) : 0; }();      // tuning knob: 10 / 8 / 12
+        static const int forced = MCAV_KNOB_INT("MCAV_SPLIT_TILE", 0);      // tuning knob: 10 / 8 / 12
         if ((forced == 10 || forced == 12 || (forced == 8 && !radj))) shape = forced;
     }
     return shape * 2 + (k64 ? 1 : 0);
@@ -1137,7 +1141,7 @@ using namespace mcav;
 // (0.129 against 0.133 ms, 0.115 against 0.112) and behind them on the 12x40 / 6x20 maps (ragged 16-wide blocks), so it is OFF by default:
 // MCAV_PATCH_F32=1, or bit 13 of mcav_igemm_desc.tile (the parity test), selects it.
 static bool patch_f32_plan(const mcav_igemm_desc* d, PatchGeo& geo) {
-    static const int enabled = [] { const char* e = getenv("MCAV_PATCH_F32"); return e ? atoi(e) : 0; }();
+    static const int enabled = MCAV_KNOB_INT("MCAV_PATCH_F32", 0);
     if (!d || (!enabled && !((d->tile >> 13) & 1))) return false;
     return patch_plan(d, geo, true);
 }

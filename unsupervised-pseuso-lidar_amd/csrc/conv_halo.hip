@@ -682,6 +682,7 @@ bool mcav_try_halo(const mcav_igemm_desc* d, hipStream_t s) {
     if ((d->tile >> 9) & 1) return false;                      // desc.tile bit 9: force the general kernels (A/B timing, parity of both)
     const bool adj = d->mode == MCAV_G_ADJ_REFLECT;
     if (adj) {
+        if (d->dact & ~0xff) return false;                     // MCAV_DACT_AFTER_ADDEND and any later flag: the table-driven kernel's epilogue honours them, this one applies act' first
         if (d->up1 || d->bias || d->act != MCAV_ACT_NONE) return false;
         if (d->pool && ((d->Hs & 1) || (d->Ws & 1))) return false;
     } else {

@@ -1874,8 +1874,8 @@ inline void launch_igemm(const IgemmParams& p_in, hipStream_t s) {
         // and applies the epilogue.
         const bool plain = !p.pool && !p.stats && p.groups <= 1 && p.y_choff == 0 && p.n_count == p.Cd && p.n_begin == 0;
         const int tiles = p.mtiles * p.ntiles, ktiles = p.Kp / T::KD * p.taps;
-        static const int enabled = [] { const char* e = getenv("MCAV_KSPLIT"); return e ? atoi(e) : 1; }();
-        static const int max_tiles = [] { const char* e = getenv("MCAV_KSPLIT_TILES"); return e ? atoi(e) : 256; }();
+        static const int enabled = MCAV_KNOB_INT("MCAV_KSPLIT", 1);
+        static const int max_tiles = MCAV_KNOB_INT("MCAV_KSPLIT_TILES", 256);
         if (enabled && plain && tiles <= max_tiles && ktiles >= 32) {
             int ksp = 1024 / tiles;
             if (ksp > 8) ksp = 8;
@@ -2015,7 +2015,7 @@ bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     p.mtiles = (p.Ktot + BM - 1) / BM;
     p.ntiles = (d->Cout + BN - 1) / BN;
     const int out_tiles = p.mtiles * p.ntiles;
-    static const int target_wgs = [] { const char* e = getenv("MCAV_WGRAD_TARGET_WGS"); const int v = e ? atoi(e) : 0; return v; }();
+    static const int target_wgs = MCAV_KNOB_INT("MCAV_WGRAD_TARGET_WGS", 0);
     int max_splits = (p.Mpix + 8 * KP - 1) / (8 * KP);           // at least 8 K-tiles each
     if (max_splits > 512) max_splits = 512;
     if (max_splits < 1) max_splits = 1;

@@ -8,6 +8,8 @@
 // L1/L2 (neighbouring pixels sample neighbouring source texels), deterministic two-level reduction
 // (wavefront shuffles -> LDS -> per-block slab -> fp64 finalize) for the 2 loss scalars and the 3x12 dP sums.
 #include <stdlib.h>
+#include <mutex>
+#include <vector>
 
 #include "mcav_common.h"
 #include "kernel_timer.h"
@@ -212,12 +214,12 @@ __device__ __forceinline__ WarpFast uniform_warp(const WarpFast& w) {
     return u;
 }
 
-// What one workgroup writes for ANOTHER to read inside the same launch (slab entries, per-sample sums) is stored and loaded at agent
-// scope (sc1: through to / from the coherence point, past the XCD-local L2), ordered by s_waitcnt in front of the ticket.  The first
-// version used __threadfence(), i.e. a write-back and invalidate of the XCD's whole L2 per workgroup: 660 (L1) / 3840 (SSIM) of those per
+// What one workgroup writes for ANOTHER to read inside the same launch (slab entries, per-sample sums) follows the hand-off protocol of
+// mcav_common.h: agent-scope (sc1) stores, an explicit s_waitcnt vmcnt(0) in every thread before the ticket, sc1 loads in the finisher.  The
+// first version used __threadfence(), i.e. a write-back and invalidate of the XCD's whole L2 per workgroup: 660 (L1) / 3840 (SSIM) of those per
 // launch took the gathers' cached lines with them and doubled the kernels' time.
-__device__ __forceinline__ void slab_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void order_before_ticket() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void slab_store(float* p, float v) { handoff_store(p, v); }
+__device__ __forceinline__ void order_before_ticket() { handoff_release(); }
 
 constexpr int RED_LD = 256 + 8;      // one pad float per 32 threads: the transposed reads are conflict-free
 
@@ -246,7 +248,7 @@ __device__ __forceinline__ void block_finish(const WLArgs& a, int b, int nblk, d
     const int tid = threadIdx.x;
     order_before_ticket();                                       // this workgroup's (agent-scope) slab stores have completed ...
     __syncthreads();
-    if (tid == 0) *s_flag = __hip_atomic_fetch_add(&a.tickets[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblk - 1);      // ... before its ticket is taken
+    if (tid == 0) *s_flag = handoff_ticket(&a.tickets[b]) == (unsigned)(nblk - 1);      // ... before its ticket is taken
     __syncthreads();
     if (!*s_flag) return;
     const float* slab = a.slab + (size_t)b * nblk * SLAB;
@@ -255,7 +257,7 @@ __device__ __forceinline__ void block_finish(const WLArgs& a, int b, int nblk, d
         const int part = tid / SLAB, k = tid - part * SLAB;
         double sum = 0.0;
         for (int blk = part; blk < nblk; blk += PARTS)
-            sum += (double)__hip_atomic_load(slab + (size_t)blk * SLAB + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // written by other workgroups
+            sum += (double)handoff_load(slab + (size_t)blk * SLAB + k);      // written by other workgroups
         s64[part][k] = sum;
     }
     __syncthreads();
@@ -281,19 +283,19 @@ __device__ __forceinline__ void block_finish(const WLArgs& a, int b, int nblk, d
             a.d_poses[(size_t)b * 12 + i] = (float)(s64[1][i] + s64[3][i]);      // pose[0]: warp 0 and (through its inverse) warp 2
             a.d_poses[(size_t)b * 12 + 6 + i] = (float)s64[2][i];
         }
-        __hip_atomic_store(a.sample_loss + b * 2 + 0, s64[0][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.sample_loss + b * 2 + 1, s64[0][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&a.tickets[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        handoff_store(a.sample_loss + b * 2 + 0, s64[0][0]);
+        handoff_store(a.sample_loss + b * 2 + 1, s64[0][1]);
+        handoff_store(&a.tickets[b], 0u);
         order_before_ticket();
-        if (__hip_atomic_fetch_add(&a.tickets[a.B], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.B - 1)) {
+        if (handoff_ticket(&a.tickets[a.B]) == (unsigned)(a.B - 1)) {
             double l0 = 0.0, l1 = 0.0;
             for (int i = 0; i < a.B; ++i) {
-                l0 += __hip_atomic_load(a.sample_loss + i * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                l1 += __hip_atomic_load(a.sample_loss + i * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                l0 += handoff_load(a.sample_loss + i * 2);
+                l1 += handoff_load(a.sample_loss + i * 2 + 1);
             }
             a.losses[0] = (float)l0;
             a.losses[1] = (float)l1;
-            __hip_atomic_store(&a.tickets[a.B], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            handoff_store(&a.tickets[a.B], 0u);
         }
     }
 }
@@ -1039,7 +1041,7 @@ inline void l1_grid(int B, int H, int W, int& G0, int& G1) {
     // MI355X (tools/loss_bench.py, network-like disparities, 12 x 192x640 / 12 x 320x1024): 1.0 -> 73.8 / 201 us, 2.0 -> 66.2 / 171, 2.7 -> 69.2 /
     // 172.  MCAV_WL_RATIO overrides (experiments).  Also measured and not kept: the smoothness tile's depths fetched a pixel ahead (68.4 us),
     // a three-stage pipeline with 24 .. 48 gathers in flight at two wavefronts per SIMD (68.6 .. 73 us).
-    static const float ratio = [] { const char* e = getenv("MCAV_WL_RATIO"); const float r = e ? (float)atof(e) : 2.0f; return r > 0.05f ? r : 2.0f; }();
+    static const float ratio = [] { const float r = MCAV_KNOB_FLOAT("MCAV_WL_RATIO", 2.0f); return r > 0.05f ? r : 2.0f; }();
     const int per_sample = slots / B > 0 ? slots / B : 1;
     int n0 = (int)((ntiles * (1.0f + 1.0f / ratio) + per_sample - 1) / per_sample);
     if (n0 < 1) n0 = 1;
@@ -1065,6 +1067,24 @@ MCAV_EXPORT size_t mcav_warp_loss_workspace_bytes(int B, int H, int W) {
     return ws_layout(B, H, W).total;
 }
 
+// The fused kernels keep their completion tickets in the caller's workspace and leave them at zero (block_finish).  A launch that returned an
+// error may not have run to that point: its workspace is remembered here and the NEXT launch on it zeroes the ticket region first (one
+// 16 KB memset on the stream, only ever after a failure) -- otherwise no later launch on that cached workspace would elect a finisher and
+// `losses` / `d_poses` would silently keep stale values.
+static std::mutex g_suspect_mu;
+static std::vector<void*> g_suspect_ws;
+static bool take_suspect(void* ws) {
+    std::lock_guard<std::mutex> lk(g_suspect_mu);
+    for (size_t i = 0; i < g_suspect_ws.size(); ++i)
+        if (g_suspect_ws[i] == ws) { g_suspect_ws.erase(g_suspect_ws.begin() + i); return true; }
+    return false;
+}
+static void mark_suspect(void* ws) {
+    std::lock_guard<std::mutex> lk(g_suspect_mu);
+    for (void* p : g_suspect_ws) if (p == ws) return;
+    g_suspect_ws.push_back(ws);
+}
+
 static int warp_loss_launch(const float* tgt, const float* ref0, const float* ref1, const float* disp_t, const float* disp_r0,
                             const float* poses, const void* K, int B, int H, int W, unsigned flags, const float* upstream,
                             const float* term_weights, float* losses, float* d_disp_t, float* d_disp_r0, float* d_poses,
@@ -1087,6 +1107,11 @@ static int warp_loss_launch(const float* tgt, const float* ref0, const float* re
     a.tw[1] = term_weights ? term_weights[1] : 0.25f;
     a.tw[2] = term_weights ? term_weights[2] : 0.5f;
     a.dbg = dbg;
+    if (take_suspect(workspace) && hipMemsetAsync(a.tickets, 0, sizeof(unsigned) * ((size_t)WL_MAX_B + 1), s) != hipSuccess) {
+        (void)hipGetLastError();
+        mark_suspect(workspace);
+        return MCAV_E_LAUNCH;
+    }
     if (flags & MCAV_WL_SSIM) {
         const dim3 wl_grid((W + TW - 1) / TW, (H + WLH - 1) / WLH, B);
         if (dbg) timed_launch(warp_loss_ssim_kernel<true>, wl_grid, dim3(256), 0, s, a);
@@ -1097,7 +1122,9 @@ static int warp_loss_launch(const float* tgt, const float* ref0, const float* re
         if (dbg) timed_launch(warp_loss_l1_kernel<true>, grid, dim3(256), 0, s, a);
         else timed_launch(warp_loss_l1_kernel<false>, grid, dim3(256), 0, s, a);
     }
-    return launch_status();
+    const int rc = launch_status();
+    if (rc != MCAV_OK) mark_suspect(workspace);
+    return rc;
 }
 
 MCAV_EXPORT int mcav_warp_loss_fwd_bwd(const float* tgt, const float* ref0, const float* ref1, const float* disp_t, const float* disp_r0,

@@ -92,6 +92,7 @@ def stream():
 
 
 _WS = {}
+_WS_RETIRED = []
 
 
 def workspace(nbytes, device, key="default", zero=False):
@@ -101,6 +102,8 @@ def workspace(nbytes, device, key="default", zero=False):
     k = (str(device), key, torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0)   # one per stream: streams overlap
     buf = _WS.get(k)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _WS_RETIRED.append(buf)       # never freed: a captured hipGraph may replay launches that have this address baked in
         alloc = torch.zeros if zero else torch.empty
         buf = alloc(max(int(nbytes), 1), dtype=torch.uint8, device=device)
         _WS[k] = buf

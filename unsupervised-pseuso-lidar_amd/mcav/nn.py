@@ -168,13 +168,14 @@ class PackRegistry:
     def __init__(self):
         self.entries = []          # (weakref to spec, kind)
         self.table = None
+        self.retired = []
         self.nblocks = 0
         self.signature = None
 
     def add(self, spec, kind):
         import weakref
         self.entries.append((weakref.ref(spec), kind))
-        self.table = None
+        self.signature = None          # the next repack rebuilds the table
 
     def _build(self, device, live):
         items = (_PackItem * len(live))()
@@ -188,6 +189,8 @@ class PackRegistry:
             it.Np, it.Kp, it.Kstride, it.first_block = np_, kp_, buf.shape[1], blk      # (buf.shape[0] = Np rows per plane x planes)
             blk += L.lib().mcav_pack_weights_blocks(it.taps, int(tr), np_, kp_)
         raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+        if self.table is not None:
+            self.retired.append(self.table)      # a captured step's re-packing launch reads the table it was captured with: never freed
         self.table = raw.to(device)
         self.nblocks = blk
 
@@ -679,14 +682,21 @@ class _WgradBatch:
         self.targets = set()      # (gradient pointer, first input channel) of the pending launches
         self.pool = {}            # (device, k) -> byte buffer of the k-th pending launch
         self.tables = {}          # bytes of the planned item array -> (device table, presum blocks, reduce blocks, lds bytes)
+        self.retired = []         # outgrown buffers: NEVER freed -- a captured hipGraph may have their addresses baked in (see buffer())
         self.device = None
 
     def buffer(self, nbytes, device):
+        """The k-th pending launch's slab buffer.  A hipGraph captured for a smaller input shape has this buffer's address (and the device
+        table that names it) baked into its nodes, so a buffer that a larger shape outgrows is retired, not freed, and the tables built for
+        it stay cached: the earlier graph keeps replaying into memory nothing else owns (tests/graph_fresh_worker.py runs
+        small-then-large StepGraphs in a fresh process).  The table cache is keyed by the item array's bytes, slab addresses included, so a
+        stale table can never be hit by a launch sequence that uses the new buffers.  Growth is monotone per k: at most a handful retire."""
         k = (str(device), len(self.items))
         buf = self.pool.get(k)
         if buf is None or buf.numel() < nbytes:
+            if buf is not None:
+                self.retired.append(buf)
             buf = self.pool[k] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-            self.tables.clear()                  # (pointers moved)
         self.device = device
         return buf
 
