@@ -17,7 +17,7 @@ def spec_of(holder, stride, pad, pad_mode, smallc=False):
     s = getattr(holder, "_mcav_spec", None)
     if s is None or s.weight is not holder.weight:
         s = N.ConvSpec(holder.weight, holder.bias, stride, pad, pad_mode, smallc)
-        s.mma = getattr(holder, "_mcav_mma", N.MMA_FP32)      # set by mcav.nn.set_compute_dtype
+        s.mma = getattr(holder, "_mcav_mma", N.DEFAULT_MMA)   # set by mcav.nn.set_compute_dtype
         holder._mcav_spec = s
     return s
 

@@ -117,13 +117,21 @@ PROFILE_LOSS = None
 PROFILE_TAGS = None
 
 
+import collections as _collections
+ProfileRec = _collections.namedtuple("ProfileRec", "kind flops i0 i1 executed bf16_planes abytes")
+
+
 class _Timed:
     """flops: the reference's algorithmic FLOPs of the launch (2 M N K of the convolution it stands for).  executed: what the MFMA pipe really
     does -- less for the merged-tap forms (4 taps instead of 9 on the upsampled half), more where K is padded (the stem's 168 k for 147)."""
 
-    def __init__(self, kind, flops, tag="", executed=None):
+    def __init__(self, kind, flops, tag="", executed=None, bf16_planes=0, abytes=0.0):
+        """bf16_planes: plane products per algorithmic product when the launch runs on the bf16 MFMA pipe (1 = plain bf16, 6 = the fp32
+        contraction on split operands), 0 = an fp32-MFMA (or non-MFMA) launch.  abytes: the launch's ALGORITHMIC bytes -- every operand
+        read once, the result written once, fp32 (the per-launch roofline is min(MFMA peak, flops / abytes x HBM peak))."""
         self.kind, self.flops, self.tag = kind, flops, tag
         self.executed = flops if executed is None else executed
+        self.bf16_planes, self.abytes = bf16_planes, abytes
 
     def __enter__(self):
         if PROFILE is not None:
@@ -132,7 +140,7 @@ class _Timed:
 
     def __exit__(self, *exc):
         if PROFILE is not None:
-            PROFILE.append((self.kind, self.flops, self.i0, L.lib().mcav_kernel_timer_count(), self.executed))
+            PROFILE.append(ProfileRec(self.kind, self.flops, self.i0, L.lib().mcav_kernel_timer_count(), self.executed, self.bf16_planes, self.abytes))
             if PROFILE_TAGS is not None:
                 PROFILE_TAGS.append(self.tag)
         return False
@@ -157,6 +165,12 @@ class _PackItem(ctypes.Structure):
 
 
 MMA_FP32, MMA_BF16, MMA_SPLIT, MMA_SPLIT_ALL = 0, 1, 2, 3      # (3: the split form on every launch the bf16 kernels cover, not only where it pays: tests)
+# What the networks' convolutions run on when nothing else is asked for (round 4): fp32 arithmetic with the kernel chosen per launch -- the
+# 3x3 stride-1 zero-padded convolutions of the ResNet trunk and their data gradients as fp32 contractions on split operands (six bf16-MFMA
+# plane products per fp32 product, fp32 accumulation: results at least as close to float64 as the fp32 MFMA's, tests/test_split_gpu.py),
+# every other launch on the fp32 MFMA kernels.  set_compute_dtype(m, "fp32-mfma") pins every launch to v_mfma_f32_32x32x2_f32.
+# A ConvSpec built directly (kernel-level tests, micro-benchmarks) stays on MMA_FP32 unless its .mma is set.
+DEFAULT_MMA = MMA_SPLIT
 # kind -> (transposed, bf16 planes: 0 = an fp32 copy, 1 = bf16, 3 = the planes h, m, l of the fp32 contraction on split operands)
 _KINDS = {"f": (False, 0), "b": (True, 0), "f16": (False, 1), "b16": (True, 1), "f16s": (False, 3), "b16s": (True, 3)}
 
@@ -343,21 +357,28 @@ class ConvSpec:
 # MMA_SPLIT weight gradients: 1 = on the split kernel (wgrad_bf16_kernel<3>), 0 = on the fp32-MFMA kernel (both are fp32 results)
 SPLIT_WGRAD = _os.environ.get("MCAV_SPLIT_WGRAD", "0") != "0"
 SPLIT_NAMES = ("fp32-split", "fp32_split", "f32s", "fp32s")
+MFMA32_NAMES = ("fp32-mfma", "fp32_mfma", "f32-mfma")
 
 
 def set_compute_dtype(module, dtype):
-    """Opt-in bf16 MFMA conv tiles for every convolution of `module` (BASELINE.json configs[2] / [4]): torch.bfloat16 / "bf16" switches the
-    launches the bf16 kernels cover (csrc/conv_bf16.hip) to bf16 operands with fp32 accumulation; torch.float32 / "fp32" switches back.
-    Master weights, activations in HBM, BatchNorm statistics and gradients stay fp32.
-    "fp32-split": the same launches as fp32 contractions carried by the bf16 MFMA -- every operand element split into three bf16 planes, six
-    plane products accumulated in fp32 (mcav_igemm_desc.mma = 2): fp32 results (at least as exact as the fp32 MFMA's) at 6 / 16 of its MFMA time."""
+    """What the convolutions of `module` compute in.
+    torch.float32 / "fp32" / None: the default -- fp32 results, kernel chosen per launch (DEFAULT_MMA: the trunk's 3x3 stride-1 convolutions and
+    their data gradients as fp32 contractions on split operands, everything else on the fp32 MFMA).
+    "fp32-mfma": every launch on the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32).
+    "fp32-split": the same launches as the default, named explicitly (mcav_igemm_desc.mma = 2): every operand element split into three bf16
+    planes, six plane products accumulated in fp32 -- fp32 results (at least as exact as the fp32 MFMA's) at 6 / 16 of its MFMA time.
+    torch.bfloat16 / "bf16": opt-in bf16 MFMA conv tiles (BASELINE.json configs[2] / [4]): the launches the bf16 kernels cover
+    (csrc/conv_bf16.hip) take bf16-rounded operands with fp32 accumulation.
+    Master weights, activations in HBM, BatchNorm statistics and gradients stay fp32 in every mode."""
     bf16 = dtype in (torch.bfloat16, "bf16", "bfloat16")
     split = dtype in SPLIT_NAMES
-    if not bf16 and not split and dtype not in (torch.float32, "fp32", "f32", "float32", None):
-        raise L.MCAVError("compute dtype must be fp32, fp32-split or bf16, got %r" % (dtype,))
+    pinned = dtype in MFMA32_NAMES
+    if not bf16 and not split and not pinned and dtype not in (torch.float32, "fp32", "f32", "float32", None):
+        raise L.MCAVError("compute dtype must be fp32, fp32-mfma, fp32-split or bf16, got %r" % (dtype,))
+    mma = MMA_BF16 if bf16 else MMA_SPLIT if split else MMA_FP32 if pinned else DEFAULT_MMA
     for m in module.modules():
         if hasattr(m, "weight") and getattr(m, "weight") is not None and m.weight.dim() == 4:
-            m._mcav_mma = MMA_BF16 if bf16 else MMA_SPLIT if split else MMA_FP32
+            m._mcav_mma = mma
             spec = getattr(m, "_mcav_spec", None)
             if spec is not None:
                 spec.mma = m._mcav_mma
@@ -381,6 +402,15 @@ def _weights_for(spec, d, transposed):
             return
     d.mma, d.w16 = 0, None
     d.w = P(spec.packed_bwd() if transposed else spec.packed_fwd())
+
+
+def _planes(d):
+    """Plane products per algorithmic product of a filled IgemmDesc / WgradDesc: 6 on the split form, 1 on plain bf16, 0 on the fp32 kernels."""
+    return 6 if d.mma >= MMA_SPLIT else 1 if d.mma == MMA_BF16 else 0
+
+
+def _pipe_tag(d):
+    return " [fp32 on split operands: 6 bf16-MFMA plane products]" if d.mma >= MMA_SPLIT else " [bf16 MFMA]" if d.mma == MMA_BF16 else ""
 
 
 def out_size(n, k, s, p):
@@ -426,7 +456,9 @@ def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0, gr
         executed = flops * ((4.0 / 9.0) * C1 + C2) / (C1 + C2)          # upsampled source: 4 merged taps instead of 9 (table kernel / halo kernel)
     if d.w_stem:
         executed = flops * (8.0 / 7.0) * (1.0 if spec.cout >= 32 else 2.0)  # the stem's K order pads 7 columns to 8; 16 outputs use half a 32-wide tile
-    with _Timed("fwd", flops, "M=%d N=%d K=%dx%d s%d %dx%d" % (B * Hd * Wd, spec.cout, spec.cin, spec.kh * spec.kw, spec.stride, Hd, Wd), executed):
+    abytes = 4.0 * (x1.numel() + (x2.numel() if x2 is not None else 0) + y.numel() + spec.weight.numel())
+    with _Timed("fwd", flops, "M=%d N=%d K=%dx%d s%d %dx%d%s" % (B * Hd * Wd, spec.cout, spec.cin, spec.kh * spec.kw, spec.stride, Hd, Wd, _pipe_tag(d)),
+                executed, _planes(d), abytes):
         L.check(h.mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(fwd)")
     return (y, slab) if stats else y
 
@@ -489,8 +521,10 @@ def conv_dgrad(spec, dy, in_shape, n_begin=0, n_count=None, out=None, dact_aux=N
         slab = empty((mt, 2, n_count), dy)
         d.stats = P(slab)
     with _Timed("dgrad", 2.0 * B * Hd * Wd * spec.cout * n_count * spec.kh * spec.kw,
-                "M=%d N=%d K=%dx%d s%d mode%d pool%d %dx%d%s" % (B * Hs * Ws, n_count, Cout, spec.kh * spec.kw, spec.stride, d.mode, int(pool), Hs, Ws,
-                                                                " +bn-bwd stats" if slab is not None else "")):
+                "M=%d N=%d K=%dx%d s%d mode%d pool%d %dx%d%s%s" % (B * Hs * Ws, n_count, Cout, spec.kh * spec.kw, spec.stride, d.mode, int(pool), Hs, Ws,
+                                                                  " +bn-bwd stats" if slab is not None else "", _pipe_tag(d)), None, _planes(d),
+                4.0 * (B * Hd * Wd * spec.cout + y.numel() * (1 + (dact_aux is not None) + (addend is not None) + (slab is not None))
+                       + spec.cout * n_count * spec.kh * spec.kw)):
         L.check(L.lib().mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(dgrad)")
     return y if slab is None else (y, slab, slab.shape[0] // bn_stats[1].groups)
 
@@ -521,7 +555,8 @@ def _dgrad_upsample_merged(spec, dy, in_shape, c1, dact_aux, dact, addend, tile)
             d.mma, d.w16 = 0, None
     with _Timed("dgrad", 2.0 * B * Hd * Wd * spec.cout * c1 * 9,
                 "M=%d N=%d K=%dx9 s1 mode2 pool1 (merged 4x4/s2) %dx%d" % (B * Hd * Wd, c1, Cout, Hd, Wd),
-                2.0 * B * (Hl + 2) * (Wl + 2) * spec.cout * c1 * 16):          # 16 taps per low-resolution pixel (incl. the ring) instead of 4 x 9
+                2.0 * B * (Hl + 2) * (Wl + 2) * spec.cout * c1 * 16, _planes(d),          # 16 taps per low-resolution pixel (incl. the ring) instead of 4 x 9
+                4.0 * (dy.numel() + B * Hl * Wl * c1 * (1 + (dact_aux is not None) + (addend is not None)) + spec.cout * c1 * 9)):
         L.check(L.lib().mcav_igemm(ctypes.byref(d), L.stream()), "mcav_igemm(dgrad, merged upsample)")
         y = empty((B, Hl, Wl, c1), dy)
         L.check(L.lib().mcav_upsample_adj_fold(P(tmp), B, Hl, Wl, c1, P(dact_aux), dact, P(addend), P(y), L.stream()), "mcav_upsample_adj_fold")
@@ -726,11 +761,13 @@ WGRAD_BATCH = _WgradBatch()
 def launch_wgrad(d, tensors, flops=0.0, tag="", executed=None):
     """mcav_wgrad for a filled descriptor (workspace handling + stream choice).  tensors: what the launch reads."""
     h = L.lib()
+    abytes = 4.0 * (sum(t.numel() for t in tensors if t is not None) + d.Cout * d.Cin * d.kh * d.kw)
     nbytes = h.mcav_wgrad_workspace_bytes(ctypes.byref(d))
     if nbytes == 0:
         raise L.MCAVError("mcav_wgrad: invalid descriptor")
 
     dev = tensors[0].device
+    planes = _planes(d) if (d.mma and h.mcav_wgrad_uses_bf16(ctypes.byref(d))) else 0
     defer = WGRAD_BATCH.enabled and dev.type == "cuda" and WGRAD_SIDE._note(torch.cuda.current_stream())
     if defer:
         # inside a backward pass: GEMM now, the slab reduction with its bucket (grads_ready / the end-of-backward join).  The descriptor is
@@ -744,7 +781,7 @@ def launch_wgrad(d, tensors, flops=0.0, tag="", executed=None):
         dd = WgradDesc.from_buffer_copy(d)
 
         def go_deferred():
-            with _Timed("wgrad", flops, tag, executed):
+            with _Timed("wgrad", flops, tag, executed, planes, abytes):
                 L.check(h.mcav_wgrad_deferred(ctypes.byref(dd), P(ws), ws.numel(), ctypes.byref(item), L.stream()), "mcav_wgrad_deferred")
         WGRAD_SIDE.run(go_deferred, tensors)
         WGRAD_BATCH.items.append(item)
@@ -752,7 +789,7 @@ def launch_wgrad(d, tensors, flops=0.0, tag="", executed=None):
 
     def go():
         ws = L.workspace(nbytes, dev, "wgrad")
-        with _Timed("wgrad", flops, tag, executed):
+        with _Timed("wgrad", flops, tag, executed, planes, abytes):
             L.check(h.mcav_wgrad(ctypes.byref(d), P(ws), ws.numel(), L.stream()), "mcav_wgrad")
     WGRAD_SIDE.run(go, tensors)
 
@@ -933,7 +970,7 @@ def narrow_ok(spec, x):
 def conv3x3r_c1_fwd(spec, x, act):
     B, H, W, C = x.shape
     y = empty((B, H, W, 1), x)
-    with _Timed("fwd", 2.0 * B * H * W * C * 9, "head M=%d N=1 K=%dx9 %dx%d" % (B * H * W, C, H, W)):
+    with _Timed("fwd", 2.0 * B * H * W * C * 9, "head M=%d N=1 K=%dx9 %dx%d" % (B * H * W, C, H, W), None, 0, 4.0 * (x.numel() + y.numel())):
         L.check(L.lib().mcav_conv3x3r_c1_fwd(P(x), B, H, W, C, P(spec.weight), P(spec.bias), act, P(y), L.stream()), "mcav_conv3x3r_c1_fwd")
     return y
 
@@ -948,7 +985,8 @@ def conv3x3r_c1_bwd(spec, x, dy, y, act, x_act, addend=None):
     dx = torch.empty_like(x)
     gw = grad_buffer(spec.weight)
     gb = grad_buffer(spec.bias) if spec.bias is not None else None
-    with _Timed("dgrad", 4.0 * B * H * W * C * 9, "head bwd (dgrad+wgrad) M=%d K=%dx9 %dx%d" % (B * H * W, C, H, W)):
+    with _Timed("dgrad", 4.0 * B * H * W * C * 9, "head bwd (dgrad+wgrad) M=%d K=%dx9 %dx%d" % (B * H * W, C, H, W), None, 0,
+                4.0 * (2 * x.numel() + dy.numel() + (addend.numel() if addend is not None else 0))):
         L.check(h.mcav_conv3x3r_c1_bwd(P(x), B, H, W, C, P(spec.weight), P(dy), P(y), act, x_act, P(addend), P(dx), P(gw), P(gb), 1,
                                        P(ws), ws.numel(), L.stream()), "mcav_conv3x3r_c1_bwd")
     return dx
