@@ -31,6 +31,8 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md); the bf16 conv stage also holds the fp32 launches the bf16 kernels do not cover
 PEAK_HBM_GBS = 8000.0
+MODE_FP32 = ("fp32 (the ResNet trunk's 3x3 stride-1 convolutions and their data gradients: fp32 contractions on split operands -- three bf16 planes per "
+             "operand, six bf16-MFMA plane products, fp32 accumulation; every other launch: fp32 MFMA)")
 def _latest(*names):
     for n in names:
         if os.path.exists(os.path.join(REPO, "profiles", n)):
@@ -38,8 +40,13 @@ def _latest(*names):
     return os.path.join(REPO, "profiles", names[-1])
 
 
-TRAFFIC_JSON = _latest("r03_traffic.json", "r02_traffic.json")      # rocprofv3 PMC passes (tools/pmc_summary.py)
-ROCPROF_CSV = _latest("r03_kernel_stats_one_stream.csv", "r02_kernel_stats_one_stream.csv")      # rocprofv3 --kernel-trace --stats of `bench.py --serial`
+TRAFFIC_JSON = _latest("r04_traffic.json", "r03_traffic.json", "r02_traffic.json")      # rocprofv3 PMC passes (tools/pmc_summary.py)
+ROCPROF_CSV = _latest("r04_kernel_stats_one_stream.csv", "r03_kernel_stats_one_stream.csv", "r02_kernel_stats_one_stream.csv")      # rocprofv3 --kernel-trace --stats of `bench.py --serial`
+
+
+def PROFILE_MODE(path):
+    """Which --dtype a committed profile was taken in: rounds 1-3 ran every contraction on the fp32 MFMA by default (today's fp32-mfma)."""
+    return "fp32" if os.path.basename(path) >= "r04" else "fp32-mfma"
 CONV_KERNELS = ("igemm_kernel", "igemm_tab_kernel", "igemm_bf16", "wgrad_kernel", "wgrad_tab_kernel", "wgrad_bf16", "conv3x3_halo", "conv3x3r_c1",
                 "stem7x7s2", "splitk_finish", "wgrad_reduce", "wgrad_presum", "patch3x3", "conv3x3_patch")
 
@@ -73,8 +80,10 @@ def measured_traffic(steps_in_profile=3):
 
 
 def workload_label(B, H, W, layers, ssim, dtype="fp32"):
+    if dtype == "fp32-mfma":
+        return "fp32-MFMA-only variant of " + workload_label(B, H, W, layers, ssim)
     if dtype == "fp32-split":
-        return "fp32-split variant of " + workload_label(B, H, W, layers, ssim)
+        dtype = "fp32"
     if dtype == "bf16":
         if (B, H, W, layers, ssim) == (12, 192, 640, 18, False):
             return "BASELINE.json configs[2] per-GPU shape"
@@ -103,8 +112,11 @@ def build(device, lr=1e-4, seed=0, depth_layers=18, ssim=False, dtype="fp32"):
     from mcav.optim import FusedAdam
     from losses import Losses
     torch.manual_seed(seed)
-    depth = DispResNet(depth_layers, dtype=torch.bfloat16 if dtype == "bf16" else "fp32-split" if dtype == "fp32-split" else None)      # bf16: the conv tiles of the depth net (98 % of the FLOPs)
-    pose = PoseNet(dtype="fp32-split") if dtype == "fp32-split" else PoseNet()
+    # fp32 (default): fp32 results, kernel per launch (mcav.nn.DEFAULT_MMA: the trunk's 3x3 stride-1 convolutions on split operands); fp32-mfma:
+    # every launch on the fp32 MFMA; bf16: the conv tiles of the depth net (98 % of the FLOPs) on bf16-rounded operands
+    net_dtype = {"fp32": None, "fp32-split": "fp32-split", "fp32-mfma": "fp32-mfma", "bf16": torch.bfloat16}[dtype]
+    depth = DispResNet(depth_layers, dtype=net_dtype)
+    pose = PoseNet(dtype=net_dtype) if dtype in ("fp32-split", "fp32-mfma") else PoseNet()
     pose.init_weights()
     depth.to(device).train()
     pose.to(device).train()
@@ -195,10 +207,12 @@ def main():
     ap.add_argument("--depth-layers", type=int, default=18, help="ResNet depth of the encoder (18 = the metric's config; 50 = BASELINE.json configs[3])")
     ap.add_argument("--ssim", action="store_true", help="photometric term = 0.85 SSIM + 0.15 L1 (Losses(ssim=True); BASELINE.json configs[3] "
                                                         "stresses this kernel) instead of the reference's live L1")
-    ap.add_argument("--dtype", choices=("fp32", "bf16", "fp32-split"), default="fp32",
-                    help="bf16: the depth net's conv tiles on the bf16 MFMA (BASELINE.json configs[2] / [4]; fp32 accumulation, fp32 master weights and "
-                         "activations in HBM); fp32-split: fp32 contractions carried by the bf16 MFMA (three bf16 planes per operand, six plane "
-                         "products, fp32 accumulation: fp32 results); the headline metric is quoted on fp32")
+    ap.add_argument("--dtype", choices=("fp32", "fp32-mfma", "fp32-split", "bf16"), default="fp32",
+                    help="fp32 (default, the headline): fp32 results, kernel chosen per launch -- the trunk's 3x3 stride-1 convolutions and their data "
+                         "gradients as fp32 contractions on split operands (three bf16 planes per operand, six bf16-MFMA plane products, fp32 "
+                         "accumulation), everything else on the fp32 MFMA; fp32-split: the same, named explicitly; fp32-mfma: every launch on "
+                         "v_mfma_f32_32x32x2_f32 (rounds 1-3's default); bf16: the depth net's conv tiles on bf16-rounded operands (BASELINE.json "
+                         "configs[2] / [4]; fp32 accumulation, fp32 master weights and activations in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--separate-passes", action="store_true", help="run the two depth passes as separate launch sets (default: stacked)")
@@ -285,13 +299,14 @@ def main():
 
     out = {"metric": "images/sec (fwd+bwd) KITTI 192x640 triplets, full training step", "value": round(value, 3), "unit": "images/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp32-split": "f32 (operands as three bf16 planes, six bf16-MFMA products, fp32 accumulate)"}[args.dtype],
+           "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "fp32-split": "f32", "fp32-mfma": "f32", "bf16": "bf16"}[args.dtype],
            "data": "synthetic",
            "config": {"workload": "%s: per-GPU batch=%d, %dx%d KITTI-shaped triplets, ResNet-%d depth encoder + 6-DoF PoseNet, "
                                   "%s, one step = 2x depth fwd + pose fwd + warp/%s/smooth loss + backward + Adam%s" %
                                   (workload_label(B, H, W, args.depth_layers, args.ssim, args.dtype),
-                                   B, H, W, args.depth_layers, {"fp32": "fp32", "bf16": "bf16 MFMA conv tiles (fp32 accumulate / storage)",
-                                                                "fp32-split": "fp32 (contractions on the bf16 MFMA over split operands)"}[args.dtype],
+                                   B, H, W, args.depth_layers,
+                                   {"fp32": MODE_FP32, "fp32-split": MODE_FP32, "fp32-mfma": "fp32, every contraction on the fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                                    "bf16": "bf16 MFMA conv tiles (fp32 accumulate / storage)"}[args.dtype],
                                    "SSIM+L1" if args.ssim else "L1", " + 1 RCCL all-reduce of the gradient arena" if world > 1 else ""),
                       "global_batch": B * world, "parallelism": "dp%d" % world},
            "loss": [round(float(l.detach()), 6) for l in loss], "hipgraph": bool(getattr(make_step, "graphed", False)),
@@ -321,19 +336,50 @@ def main():
             eager_step(collective=False)      # instrumented launches must be issued eagerly (events are not graph nodes)
         torch.cuda.synchronize()
         durs = N.kernel_timer_end()
-        recs = [(kind, fl, sum(durs[i0:i1])) for (kind, fl, i0, i1, _) in N.PROFILE]
+        prof = N.PROFILE
+        recs = [(r.kind, r.flops, sum(durs[r.i0:r.i1])) for r in prof]
         # the slab reduction of a weight gradient = every dispatch of its record after the first (the GEMM); round 2's figure left it out
         # ... or, for the batched form the step really runs (one presum + one reduce launch per gradient bucket), a record of its own without FLOPs
-        slab_ms = sum(sum(durs[(i0 + 1 if fl else i0):i1]) for (kind, fl, i0, i1, _) in N.PROFILE if kind == "wgrad") / 3.0
-        executed_flops = sum(ex for (_, _, _, _, ex) in N.PROFILE) / 3.0
+        slab_ms = sum(sum(durs[(r.i0 + 1 if r.flops else r.i0):r.i1]) for r in prof if r.kind == "wgrad") / 3.0
+        executed_flops = sum(r.executed for r in prof) / 3.0
         N.PROFILE = None
         streams.SERIAL = serial_before
+        # every launch against ITS OWN ceiling, min(MFMA peak of the pipe it runs on, arithmetic intensity x HBM peak) with the
+        # launch's algorithmic bytes (operands read once, result written once).  A launch of the split form executes six bf16-MFMA plane
+        # products per fp32 product, so its MFMA ceiling in fp32-equivalent FLOPs is the bf16 peak / 6.
+        def bound_of(r):
+            mfma = PEAK_BF16_MFMA_TFLOPS / r.bf16_planes if r.bf16_planes else PEAK_F32_MFMA_TFLOPS
+            hbm = (r.flops / r.abytes) * PEAK_HBM_GBS / 1e3 if r.abytes > 0 else float("inf")
+            return (mfma, "mfma") if mfma <= hbm else (hbm, "hbm")
+        n1 = len(prof) // 3
+        last = [(r, sum(durs[r.i0:r.i1])) for r in prof[2 * n1:]]
         if args.layer_report:
             tags, N.PROFILE_TAGS = N.PROFILE_TAGS, None
-            n1 = len(recs) // 3
             with open(args.layer_report, "w") as f:
-                for (kind, fl, ms1), tag in zip(recs[2 * n1:], tags[2 * n1:]):
-                    f.write("%-6s %-58s %8.2f GF %8.3f ms %7.2f TF/s\n" % (kind, tag, fl / 1e9, ms1, fl / (ms1 * 1e-3) / 1e12))
+                f.write("# kind tag | algorithmic GF | ms | TF/s | algorithmic MB | FLOP/B | bound TF/s = min(MFMA peak of the pipe, FLOP/B x 8 TB/s) | fraction of that bound\n")
+                for (r, ms1), tag in zip(last, tags[2 * n1:]):
+                    if not r.flops:
+                        f.write("%-6s %-96s %8.2f GF %8.3f ms\n" % (r.kind, tag, 0.0, ms1))
+                        continue
+                    bd, which = bound_of(r)
+                    tf = r.flops / (ms1 * 1e-3) / 1e12
+                    f.write("%-6s %-96s %8.2f GF %8.3f ms %7.2f TF/s %8.1f MB %7.1f F/B  bound %6.1f (%s)  frac %.3f\n" %
+                            (r.kind, tag, r.flops / 1e9, ms1, tf, r.abytes / 1e6, r.flops / max(r.abytes, 1.0), bd, which, tf / bd))
+        per_class = {}
+        for r, ms1 in last:
+            if not r.flops:
+                continue
+            bd, which = bound_of(r)
+            pipe = "bf16-mfma x%d planes" % r.bf16_planes if r.bf16_planes else "f32-mfma"
+            c = per_class.setdefault("%s | %s | %s-bound" % (r.kind, pipe, which), {"launches": 0, "gflop": 0.0, "ms": 0.0, "bound_ms": 0.0})
+            c["launches"] += 1
+            c["gflop"] += r.flops / 1e9
+            c["ms"] += ms1
+            c["bound_ms"] += r.flops / (bd * 1e12) * 1e3            # the time the launch would take AT its own ceiling
+        for c in per_class.values():
+            c["tflops"] = round(c["gflop"] / c["ms"], 2)
+            c["frac_of_bound"] = round(c["bound_ms"] / c["ms"], 4)   # time-weighted: sum of ceiling times / sum of measured times
+            c["gflop"], c["ms"], c["bound_ms"] = round(c["gflop"], 2), round(c["ms"], 4), round(c["bound_ms"], 4)
         lrecs = [durs[i0:i1] for (_, i0, i1) in N.PROFILE_LOSS if i1 - i0 == 1]      # the forward call's ONE launch (the backward's re-run is a device-side no-op)
         N.PROFILE_LOSS = None
         ms = sum(t for (_, _, t) in recs) / 3.0
@@ -349,16 +395,40 @@ def main():
         if args.ssim:
             warp_traffic = None
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        if args.dtype != "fp32":
-            conv_traffic = None
+        mode = "fp32" if args.dtype == "fp32-split" else args.dtype
+        if mode != PROFILE_MODE(TRAFFIC_JSON):
+            conv_traffic = None                                    # (the committed PMC passes are of the mode they were taken in)
+        # the two MFMA pipes apart: fp32-equivalent FLOPs of the launches that run the fp32 MFMA over its peak, and the bf16-MFMA FLOPs really
+        # executed (planes x algorithmic) by the launches on the bf16 pipe over ITS peak
+        f32_l = [(r, t) for r, t in last if r.flops and not r.bf16_planes]
+        b16_l = [(r, t) for r, t in last if r.flops and r.bf16_planes]
+        pipes = {}
+        if f32_l:
+            fl, t = sum(r.flops for r, _ in f32_l), sum(t for _, t in f32_l)
+            pipes["f32_mfma"] = {"launches": len(f32_l), "algorithmic_gflop": round(fl / 1e9, 2), "ms": round(t, 3), "tflops": round(fl / t / 1e9, 2),
+                                 "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(fl / t / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)}
+        if b16_l:
+            fl, t = sum(r.flops for r, _ in b16_l), sum(t for _, t in b16_l)
+            ex = sum(r.flops * r.bf16_planes for r, _ in b16_l)
+            pipes["bf16_mfma"] = {"launches": len(b16_l), "algorithmic_gflop": round(fl / 1e9, 2), "executed_bf16_gflop": round(ex / 1e9, 2), "ms": round(t, 3),
+                                  "algorithmic_tflops": round(fl / t / 1e9, 2), "executed_bf16_tflops": round(ex / t / 1e9, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
+                                  "frac": round(ex / t / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                  "algorithmic_over_f32_mfma_peak": round(fl / t / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
+                                  "note": "algorithmic_over_f32_mfma_peak may exceed 1: these launches do not run on the fp32 MFMA instruction; "
+                                          "frac is what they execute over the pipe they do run on"}
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(ach / peak, 4), "traffic": conv_traffic,
+                           "frac_note": ("frac = the reference's algorithmic fp32 FLOPs of the whole conv stage over the fp32 MFMA instruction peak (157.3); part of the "
+                                         "stage runs on the bf16 pipe (`pipes`), so this is a work-rate figure that an fp32-MFMA-only kernel set cannot exceed 1 on "
+                                         "but this one could -- read `pipes` and `per_class` for each launch class against its own ceiling") if b16_l and args.dtype != "bf16" else None,
+                           "pipes": pipes, "per_class": per_class,
                            "executed_frac": round(executed_flops / (ms * 1e-3) / 1e12 / peak, 4),
                            "executed_gflop_per_step": round(executed_flops / 1e9, 2),
-                           "executed_note": "frac counts the reference's algorithmic FLOPs (2 M N K of every convolution); executed_frac counts what the MFMA "
-                                            "pipe does: 4 / 9 of the upsampled half in the merged-tap launches, 168 / 147 in the stem kernels",
+                           "executed_note": "frac counts the reference's algorithmic FLOPs (2 M N K of every convolution); executed_frac counts the products the "
+                                            "kernels form: 4 / 9 of the upsampled half in the merged-tap launches, 168 / 147 in the stem kernels (plane products "
+                                            "of the split form are in pipes.bf16_mfma)",
                            "traffic_note": "HBM bytes of the conv stage per step, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the rocprofv3 --pmc passes "
-                                           "in profiles/r02_traffic.json (null when absent)",
+                                           "in %s (null when no pass of this mode is committed)" % os.path.relpath(TRAFFIC_JSON, REPO),
                            "kernel": "conv stage = implicit-GEMM forward / adjoint, weight-gradient (GEMM + its slab reduction: presum + reduce), halo and "
                                      "stencil kernels, all launches of one step; durations from per-dispatch HIP start/stop events",
                            "frac_excluding_slab_reduction": round(flops / ((ms - slab_ms) * 1e-3) / 1e12 / peak, 4),
@@ -367,11 +437,7 @@ def main():
                            "kernel_ms_per_step": round(ms, 3),
                            "by_kind": {k: {"gflop": round(v[0] / 1e9, 2), "ms": round(v[1], 3), "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2),
                                            "launches": v[2] // 3} for k, v in by_kind.items()}}
-        if args.dtype == "fp32-split":
-            out["roofline"]["split_note"] = ("frac = the reference's algorithmic fp32 FLOPs over the fp32 MFMA peak, as for --dtype fp32 (same work, same results to fp32 "
-                                             "rounding); the 3x3 stride-1 zero-padded convolutions and their data gradients run six bf16 MFMA products per fp32 "
-                                             "product on the bf16 pipe (peak %.0f TFLOP/s), every other launch on the fp32 MFMA kernels" % PEAK_BF16_MFMA_TFLOPS)
-        rp_ms = rocprof_conv_ms_per_step() if (B, H, W, args.depth_layers, args.dtype, args.ssim) == (12, 192, 640, 18, "fp32", False) else None
+        rp_ms = rocprof_conv_ms_per_step() if (B, H, W, args.depth_layers, mode, args.ssim) == (12, 192, 640, 18, PROFILE_MODE(ROCPROF_CSV), False) else None
         if rp_ms:
             out["roofline"]["frac_rocprof"] = round(flops / (rp_ms * 1e-3) / 1e12 / peak, 4)
             out["roofline"]["rocprof_kernel_ms_per_step"] = round(rp_ms, 3)
@@ -389,6 +455,9 @@ def main():
         # SURVEY.md 8d asks for 3 warm-up + 10 timed steps: taken when the run itself is the full-length one (--steps >= 100, the default)
         full = args.steps >= 100
         out["cpu_baseline"] = cpu_baseline(H, W, args.depth_layers, args.ssim, warm=3 if full else 1, steps=10 if full else 5)
+        if full and B != 4:
+            # SURVEY.md 8d names B = 4 AND the metric's own batch: a second, shorter sample at this run's batch (1 warm-up + 3 timed steps, ~45 s at 12)
+            out["cpu_baseline"]["at_bench_batch"] = cpu_baseline(H, W, args.depth_layers, args.ssim, batch=B, warm=1, steps=3)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -117,18 +117,23 @@ def test_fused_adam_loads_a_torch_adam_checkpoint():
 
 
 def test_compute_dtype_names_select_the_contraction_form():
-    """mcav.nn.set_compute_dtype: fp32 (default, fp32 MFMA), bf16 (BASELINE.json configs[2] / [4]) and fp32-split (fp32 contractions on the bf16
-    MFMA over split operands, mcav_igemm_desc.mma = 2) mark every convolution of a module; anything else is refused.  Host logic only."""
+    """mcav.nn.set_compute_dtype: fp32 (the default since round 4: fp32 results, the trunk's 3x3 stride-1 convolutions as fp32 contractions on split
+    operands, mcav_igemm_desc.mma = 2), fp32-mfma (every launch on the fp32 MFMA), fp32-split (the default's form, named), bf16 (BASELINE.json
+    configs[2] / [4]) mark every convolution of a module; anything else is refused.  Host logic only."""
     import pytest
     import torch
+    from mcav import depthnet as E
     from mcav import nn as N
     from mcav.lib import MCAVError
     from models.depth.resnet_dispnet import DispResNet
     net = DispResNet(18)
     convs = [m for m in net.modules() if getattr(m, "weight", None) is not None and m.weight.dim() == 4]
-    assert convs and all(getattr(m, "_mcav_mma", N.MMA_FP32) == N.MMA_FP32 for m in convs)
+    assert N.DEFAULT_MMA == N.MMA_SPLIT
+    assert convs and all(not hasattr(m, "_mcav_mma") for m in convs)                       # untouched modules take the default ...
+    assert E.spec_of(net.encoder.encoder.layer1[0].conv1, 1, 1, N.PAD_ZERO).mma == N.DEFAULT_MMA      # ... when the engine builds their ConvSpec
+    assert N.ConvSpec(convs[0].weight, None, 1, 1, N.PAD_ZERO).mma == N.MMA_FP32           # a ConvSpec built directly (kernel tests) is pinned
     for name, want in (("bf16", N.MMA_BF16), (torch.bfloat16, N.MMA_BF16), ("fp32-split", N.MMA_SPLIT), ("f32s", N.MMA_SPLIT),
-                       ("fp32", N.MMA_FP32), (torch.float32, N.MMA_FP32)):
+                       ("fp32-mfma", N.MMA_FP32), ("fp32", N.DEFAULT_MMA), (torch.float32, N.DEFAULT_MMA), (None, N.DEFAULT_MMA)):
         N.set_compute_dtype(net, name)
         assert all(m._mcav_mma == want for m in convs), name
     with pytest.raises(MCAVError):
