@@ -63,8 +63,10 @@ typedef struct mcav_igemm_desc {
     const float* addend;    /* same layout as y */
     int pool;               /* 1: destination pixels are visited in 2x2 blocks and summed: y is [B, Hd/2, Wd/2, Cd] */
     float* stats;           /* NULL or [mtiles][2][n_count]: per-tile column sums of y and y^2 (BatchNorm batch statistics) */
-    int tile;               /* 0 = choose automatically; else a tile-config id in the low byte; bits 8-13 = test / tuning switches that force or forbid one
-                             * of the kernel forms (bit 13: the fp32 patch-in-LDS kernel for 3x3 stride-1 zero-padded launches) */
+    int tile;               /* 0 = choose automatically; else a tile-config id in the low byte; bits 8-15 = test / tuning switches that force or forbid one
+                             * of the kernel forms (bit 13: the fp32 patch-in-LDS kernel for 3x3 stride-1 zero-padded launches; bit 14: the second
+                             * patch kernel of the split form -- 128- / 256-row tiles, LDS-DMA filter ring, one workgroup per CU --, bit 15: its
+                             * 128 x 32 configuration at two workgroups per CU) */
     int groups;             /* 0/1 = one group.  G > 1: the batch is G equal groups (e.g. the tgt and ref0 passes of the depth net run as
                              * one launch); output tiles never straddle a group, so `stats` rows [g * mtiles/G, (g+1) * mtiles/G) belong to
                              * group g (per-pass BatchNorm statistics).  Only with the DIRECT / SMALLC gathers and pool == 0. */
@@ -236,7 +238,9 @@ int mcav_nchw3_to_nhwc(const float* s0, const float* s1, const float* s2, int B,
 int mcav_bn_finalize(const float* stats, int mtiles, int C, double count, const float* gamma, const float* beta, float eps,
                      float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* save_mean,
                      float* save_invstd, int groups, void* workspace, size_t workspace_bytes, void* stream);
-/* Layers with many tiles are reduced in two stages (fp64 partials in `workspace`); 0 bytes = the workspace may be NULL. */
+/* Layers with many tiles are reduced in two stages inside ONE launch (fp64 partials and one completion ticket per 64 channels in
+ * `workspace`): the workspace must be ZERO-FILLED when it is allocated; every launch leaves the tickets at zero, so a cached workspace serves
+ * any number of launches issued one after the other on a stream (not two launches at once).  0 bytes = the workspace may be NULL. */
 size_t mcav_bn_finalize_workspace_bytes(int mtiles, int C, int groups);
 /* groups > 1: `stats` holds groups * mtiles rows, `count` is per group, scale/shift/save_* are [groups][C], and the running
  * statistics are updated once per group, in group order (exactly as `groups` consecutive forward passes would). */
@@ -305,6 +309,16 @@ int mcav_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * lr, grad_scale, and five words the call owns }.  The host sets step / lr / grad_scale; every call advances the count by one. */
 int mcav_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float beta1, float beta2, float eps,
                        float* state8, void* stream);
+
+/* External events of a hipGraph-captured step (BASELINE.json configs[4]: "hipGraph-captured step + overlapped all-reduce"; the reference has no
+ * counterpart -- the slot is between loss.backward() and optimizer.step(), trainer.py:264-266).  mcav_event_record_external on a CAPTURING
+ * stream adds an external event-record node (hipEventRecordExternal): every replay signals the event when the graph reaches the node, and
+ * work outside the graph (a gradient bucket's all-reduce on a communication stream) orders itself behind it with mcav_stream_wait_event.
+ * On a stream that is not capturing the record is an ordinary one.  Events are created without timing. */
+int mcav_event_create(void** event);
+int mcav_event_destroy(void* event);
+int mcav_event_record_external(void* event, void* stream);
+int mcav_stream_wait_event(void* stream, void* event);
 
 #ifdef __cplusplus
 }

@@ -50,16 +50,23 @@ def main():
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--dtype", default="fp32")
     args = ap.parse_args()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(args.port), RANK=str(args.rank), WORLD_SIZE=str(args.world), LOCAL_RANK="0",
                       MCAV_DP_OVERLAP=str(args.overlap))
+    if args.world == 1:
+        os.environ["MCAV_DP_FORCE"] = "1"             # a 1-rank group still takes the collective path (the RCCL dry run of test_dist_gpu.py)
     import torch
     from mcav import dist as mdist
-    mdist.init_from_env("gloo")                       # gloo: several ranks on one GPU (RCCL needs one GPU per rank)
+    mdist.init_from_env(args.backend)                 # gloo: several ranks on one GPU (RCCL needs one GPU per rank: "nccl" only with --world 1)
     from oracle.step import synthetic_batch
     from trainer import Trainer
     H, W, B = 64, 128, 4
     t = Trainer(build_config(H, W, B // args.world, args.graph))
+    if args.dtype != "fp32":
+        from mcav import nn as N
+        N.set_compute_dtype(t.depth_model, args.dtype)
     seed_models(t)
     t.set_train()
     for k in range(args.steps):
@@ -67,8 +74,10 @@ def main():
         t.train_step(s)
     torch.cuda.synchronize()
     opt = t.model_optimizer
-    torch.save({"gflat": opt.arena().gflat.cpu(), "flat": opt.arena().flat.cpu(), "scale": opt.grad_scale,
-                "buckets": list(getattr(mdist._SYNC.get(id(opt.arena())), "last_buckets", []))}, args.out)
+    g = getattr(t, "_graphs", None)
+    marks = max([len(gs.marks) for gs in g.graphs.values()], default=0) if g is not None else 0
+    torch.save({"gflat": opt.arena().gflat.cpu(), "flat": opt.arena().flat.cpu(), "scale": opt.grad_scale, "backend": torch.distributed.get_backend(),
+                "buckets": list(getattr(mdist._SYNC.get(id(opt.arena())), "last_buckets", [])), "graph_marks": marks}, args.out)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

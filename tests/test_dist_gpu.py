@@ -23,12 +23,12 @@ def _free_port():
     return p
 
 
-def run_ranks(tmp_path, overlap, graph, steps=1, world=2):
+def run_ranks(tmp_path, overlap, graph, steps=1, world=2, backend="gloo", dtype="fp32"):
     port = _free_port()
     outs = [str(tmp_path / ("rank%d_o%d_g%d.pt" % (r, overlap, graph))) for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, WORKER, "--rank", str(r), "--world", str(world), "--port", str(port), "--overlap", str(overlap),
-                               "--graph", str(graph), "--steps", str(steps), "--out", outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               "--graph", str(graph), "--steps", str(steps), "--out", outs[r], "--backend", backend, "--dtype", dtype], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]
     logs = []
     for p in procs:
@@ -79,9 +79,14 @@ def test_two_ranks_equal_one_process_accumulating_the_halves(tmp_path, overlap, 
     err = float((r0["gflat"] - gsum).norm() / gsum.norm())
     assert err < 1e-6, err
     assert float((r0["flat"] - flat).abs().max()) < 1e-6
-    if overlap and not graph:
-        # the decoder and layer4 buckets went out during backward: more than one collective, covering the arena exactly once
-        assert len(r0["buckets"]) >= 3 and sum(r0["buckets"]) == 4 * gsum.numel()
+    if overlap:
+        # the decoder and layer4 buckets went out during backward: more than one collective, covering the arena exactly once.  Under hipGraph
+        # replay too (round 4): the captured backward carries external event-record nodes at the bucket boundaries and each bucket's
+        # collective waits for its event on the communication stream (mcav/graph.py) -- BASELINE.json configs[4]'s "hipGraph-captured step +
+        # overlapped all-reduce" as ONE mode, bit-equal in its result to the eager step.
+        assert len(r0["buckets"]) >= 3 and sum(r0["buckets"]) == 4 * gsum.numel(), r0["buckets"]
+        if graph:
+            assert r0["graph_marks"] >= 2, r0
     else:
         assert sum(r0["buckets"]) in (0, 4 * gsum.numel())
 
@@ -93,3 +98,38 @@ def test_two_ranks_stay_equal_over_steps_under_graph_replay(tmp_path):
     assert torch.equal(r0["flat"], r1["flat"])
     _, flat = single_process_reference(steps=3)
     assert float((r0["flat"] - flat).abs().max()) < 5e-6
+
+
+def test_one_rank_over_rccl_runs_the_collective_path(tmp_path):
+    """what the gloo rehearsals do not exercise -- communicator initialisation with backend="nccl" (RCCL) bound to
+    the device (init_process_group(device_id=...)), the collectives' own stream and the ordering of Work.wait() against the Adam launch.  One
+    rank on the one GPU of this box, WORLD_SIZE = 1 forced through the collective code path (MCAV_DP_FORCE=1: mcav.dist treats a 1-rank
+    group as data parallel), bucketed overlap on, three steps eager and three under hipGraph replay: the result must equal the plain
+    single-process step bit for bit (an all-reduce over one rank is the identity, grad_scale = 1)."""
+    outs = {}
+    for graph in (0, 1):
+        (r0,) = run_ranks(tmp_path, 1, graph, steps=3, world=1, backend="nccl")
+        assert r0["backend"] == "nccl" and r0["scale"] == 1.0
+        assert len(r0["buckets"]) >= 3, r0["buckets"]
+        outs[graph] = r0
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import dp_worker as W
+    from oracle.step import synthetic_batch
+    from trainer import Trainer
+    t = Trainer(W.build_config(64, 128, 4, 0))
+    W.seed_models(t)
+    t.set_train()
+    for k in range(3):
+        t.train_step(synthetic_batch(4, 64, 128, seed=70 + k))
+    torch.cuda.synchronize()
+    flat = t.model_optimizer.arena().flat.cpu()
+    assert torch.equal(outs[0]["flat"], flat), "eager step over RCCL (1 rank) differs from the plain step: max %.3e" % float((outs[0]["flat"] - flat).abs().max())
+    assert float((outs[1]["flat"] - flat).abs().max()) <= 1e-6 * float(flat.abs().max())      # (replay = the one-stream schedule: 1e-6, as test_graph_gpu)
+
+
+def test_two_ranks_bf16_conv_tiles_stay_equal(tmp_path):
+    """configs[2] / [4] rehearsal: the two-rank run once with the bf16 MFMA conv tiles (eager, bucketed overlap): ranks hold bit-equal
+    parameters after two steps and the reduced gradient is finite."""
+    r0, r1 = run_ranks(tmp_path, 1, 0, steps=2, dtype="bf16")
+    assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["gflat"], r1["gflat"])
+    assert torch.isfinite(r0["gflat"]).all() and len(r0["buckets"]) >= 3

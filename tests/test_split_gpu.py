@@ -257,3 +257,41 @@ def test_split_non_finite_operands_give_non_finite_results_where_the_fp32_kernel
         assert torch.equal(bad["split"][i][same], clean["split"][i][same]), what          # untouched outputs are bit-identical
     # the 3x3 neighbourhood of each bad pixel, every output channel
     assert int((~torch.isfinite(bad["split"][0])).sum()) == 2 * 9 * C
+
+
+@pytest.mark.parametrize("tile_bits", [1 << 14, 3 << 14])
+@pytest.mark.parametrize("case", [(4, 12, 20, 64, 64), (4, 24, 48, 64, 128), (6, 6, 20, 128, 96), (2, 48, 32, 32, 64)])
+def test_second_patch_kernel_matches_float64_as_the_first_one_does(case, tile_bits):
+    """conv3x3_patch2_kernel (csrc/conv_bf16.hip; opt-in through mcav_igemm_desc.tile bits 14 / 15: measured level with the first patch kernel, so
+    it is off by default): several 64-pixel sub-blocks -- of different images on the small maps -- per workgroup, filter tiles by LDS-DMA into a
+    two-stage ring whose LDS image is permuted on the SOURCE side.  Forward with bias + ReLU + grouped BatchNorm statistics, and the data
+    gradient, against float64: the same error as the first kernel's (both are the six-product split form)."""
+    from mcav import nn as N
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case) + tile_bits % 97)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(1, Cin, 1, 1, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = 0.1 * torch.randn(Cout, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    want = torch.relu(ref_conv64(x, w, b, 1, 1, 0))
+    raw = ref_conv64(x, w, None, 1, 1, 0)
+    xr = x.double().requires_grad_()
+    ref_conv64(xr, w.double(), None, 1, 1, 0).backward(dy.double())
+    errs = {}
+    for name, tile in (("first", 0), ("second", tile_bits)):
+        spec = spec_of(w, b, 1, 1, 0, N.MMA_SPLIT)
+        y = N.conv_fwd(spec, nhwc(x), act=N.ACT_RELU, tile=tile)
+        dx = N.conv_dgrad(spec, nhwc(dy), (H, W), tile=tile)
+        spec0 = spec_of(w, None, 1, 1, 0, N.MMA_SPLIT)
+        yraw, slab = N.conv_fwd(spec0, nhwc(x), stats=True, groups=2, tile=tile)
+        mt = slab.shape[0] // 2
+        s0 = torch.stack([slab[grp * mt:(grp + 1) * mt].double().sum(0).cpu() for grp in range(2)])      # [group][sum | sum of squares][channel]
+        part = [raw[grp * (B // 2):(grp + 1) * (B // 2)] for grp in range(2)]
+        errs[name] = (rel_err(nchw(y), want), rel_err(nchw(dx), xr.grad), rel_err(nchw(yraw), raw),
+                      max(rel_err(s0[grp][0], part[grp].sum((0, 2, 3))) for grp in range(2)),
+                      max(rel_err(s0[grp][1], (part[grp] ** 2).sum((0, 2, 3))) for grp in range(2)), slab.shape[0])
+    print("patch kernels %s bits %x: first %s | second %s" % (case, tile_bits, ["%.1e" % e for e in errs["first"][:5]], ["%.1e" % e for e in errs["second"][:5]]))
+    assert errs["second"][5] < errs["first"][5], "the second kernel did not run (same statistics rows as the first)"
+    for es, ef in zip(errs["second"][:3], errs["first"][:3]):
+        assert es < 3e-6 and no_worse(es, ef), errs
+    assert errs["second"][3] < 3e-5 and errs["second"][4] < 3e-6, errs

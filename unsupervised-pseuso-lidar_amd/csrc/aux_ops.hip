@@ -266,3 +266,41 @@ MCAV_EXPORT int mcav_upsample_nearest2x_bwd(const float* grad_out, size_t planes
     upsample_nearest2x_bwd_kernel<<<aux_grid(planes * h * w, 8192), 256, 0, as_stream(stream)>>>(grad_out, planes, h, w, grad_in);
     return launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------- external events of a captured step
+// A hipGraph-captured training step that must hand data to work OUTSIDE the graph while it is still running (the gradient buckets of
+// mcav/dist.py: all-reduced on a communication stream while the rest of the backward pass replays) marks the hand-off points with external
+// event-record nodes: hipEventRecordWithFlags(..., hipEventRecordExternal) on the capturing stream.  On every replay the node records the
+// event when the graph gets there; a stream outside the graph waits for it with mcav_stream_wait_event before its collective is issued.
+MCAV_EXPORT int mcav_event_create(void** event) {
+    if (!event) return MCAV_E_INVALID;
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return MCAV_E_LAUNCH; }
+    *event = e;
+    return MCAV_OK;
+}
+
+MCAV_EXPORT int mcav_event_destroy(void* event) {
+    if (!event) return MCAV_E_INVALID;
+    return hipEventDestroy(reinterpret_cast<hipEvent_t>(event)) == hipSuccess ? MCAV_OK : MCAV_E_LAUNCH;
+}
+
+// Under stream capture: an external event-record node (the event is signalled by each replay, for waiters outside the graph).  On a stream
+// that is not capturing: a plain hipEventRecord.
+MCAV_EXPORT int mcav_event_record_external(void* event, void* stream) {
+    if (!event) return MCAV_E_INVALID;
+    hipStream_t s = as_stream(stream);
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return MCAV_E_LAUNCH; }
+    const hipError_t e = st == hipStreamCaptureStatusActive ? hipEventRecordWithFlags(reinterpret_cast<hipEvent_t>(event), s, hipEventRecordExternal)
+                                                           : hipEventRecord(reinterpret_cast<hipEvent_t>(event), s);
+    if (e != hipSuccess) { (void)hipGetLastError(); return MCAV_E_LAUNCH; }
+    return MCAV_OK;
+}
+
+MCAV_EXPORT int mcav_stream_wait_event(void* stream, void* event) {
+    if (!event) return MCAV_E_INVALID;
+    if (hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(event), 0) != hipSuccess) { (void)hipGetLastError(); return MCAV_E_LAUNCH; }
+    return MCAV_OK;
+}
+

@@ -621,6 +621,279 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
 template <int NS, int TMB>
 constexpr size_t patch_lds_bytes() { return sizeof(u16) * (size_t)NS * (PatchCfg<TMB>::PIX + 3 * 64) * 32 + sizeof(unsigned) * 64 * TMB; }
 
+// ------------------------------------------------------------------------------------------------ patch kernel, second form (round 4)
+// What the counters said about conv3x3_patch_kernel (profiles/r03_pmc_patch_kernel.txt): its MFMA pipe is busy a third of
+// the time because (a) every 64- / 128-pixel block streams the whole filter from L2 (20 B / clk / CU at most, latency-bound by the bytes a
+// wavefront's registers keep in flight), (b) a stage is 36-72 MFMAs between two barriers, (c) set-up and epilogue of a 10 us workgroup.
+// This form gives a workgroup SB sub-blocks of 64 output pixels (each a TH x TW block of one image: any of the 4 x 16 / 3 x 20 / 6 x 10 /
+// 8 x 8 shapes the planner picks per map) x 64 outputs = a 128- or 256-row tile -- the filter stream per FLOP falls 2-4x and the 6x20 / 12x40
+// maps (60-pixel blocks) fill whole MFMA tiles with blocks of several images --, runs ONE workgroup per CU (one wavefront per SIMD, the whole
+// register file: 64 x 64 per wavefront at SB = 4, twelve 32x32 accumulators) and moves the filter tiles by LDS-DMA (global_load_lds_dwordx4:
+// no registers, no ds_write pass) into a two-stage ring, so that stage s + 1 lands while stage s is multiplied and a stage is ONE barrier.
+// LDS image of a filter tile = the first kernel's (64-byte rows, 16-byte slots XOR-ed by (row >> 2) & 3), obtained by permuting the SOURCE
+// slot each lane fetches (an LDS-DMA instruction writes its 64 x 16 bytes linearly).  The patch still goes through registers (it is
+// converted / split on the way), once per 32-channel chunk.  Same epilogue, same statistics slab (rows = workgroup rows).
+// Timing experiments only, WRONG results (make variant NAME=p2d1 FLAGS=-DMCAV_PATCH2_DIAG=1): 1 no filter DMA in the loop, 2 no MFMAs, 4 no
+// epilogue, 8 no patch staging in the loop.  Zero in the shipped library.
+#ifndef MCAV_PATCH2_DIAG
+#define MCAV_PATCH2_DIAG 0
+#endif
+
+template <int SB, int BN_>
+struct Patch2Cfg {
+    static constexpr int BM = 64 * SB, BN = BN_;
+    static constexpr int PIX = 110;                       // patch pixels of one sub-block (PatchCfg<1>::PIX)
+    static constexpr int VP = SB * PIX;                   // patch pixels of the workgroup
+    static constexpr int NJ = (VP + 31) / 32;             // ... staged per thread
+    // four wavefronts stacked along M: 64 x 64 each (SB = 4: a wavefront = a sub-block) or 32 x 64 (SB = 2: two wavefronts per sub-block)
+    // BN = 32 (a 128 x 32 tile, 79 KB of LDS): TWO workgroups per CU, so that one's set-up, epilogue and DMA waits run beside the other's MFMAs
+    using T = typename std::conditional<SB == 4, BTile<256, BN_, 64, BN_, 32, 32>, BTile<128, BN_, 32, BN_, 32, 32>>::type;
+};
+
+template <int NS, int SB, int BN>
+constexpr size_t patch2_lds_bytes() { return sizeof(u16) * (size_t)NS * (SB * 110 + 2 * 3 * BN) * 32 + sizeof(unsigned) * 64 * SB; }
+
+template <int NS, int SB, int BN>
+__global__ __launch_bounds__(256, BN == 32 ? 2 : 1) void conv3x3_patch2_kernel(IgemmParams p, const u16* __restrict__ w16, PatchGeo geo) {
+    using C = Patch2Cfg<SB, BN>;
+    using T = typename C::T;
+    constexpr int BM = C::BM, CKT = 32, LDH = 32, PIX = C::PIX, TM = T::TM, TN = T::TN;
+    constexpr int APL = PIX * LDH;                               // one plane of one sub-block's patch, in elements
+    constexpr int BPL = BN * LDH;                                // one (tap, plane) filter tile
+    constexpr int BSTAGE = 3 * NS * BPL;                         // a stage: three taps x planes
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    u16* const Ap = reinterpret_cast<u16*>(s_raw);                                     // [SB][NS][PIX][LDH]
+    u16* const Bs = Ap + SB * NS * APL;                                                // [2][3 taps][NS][BN][LDH]
+    unsigned* const s_out = reinterpret_cast<unsigned*>(Bs + 2 * BSTAGE);              // [BM] byte offset of each row's output pixel (OOB: none)
+    float (*const s_stat)[2][BN] = reinterpret_cast<float (*)[2][BN]>(Bs);
+    static_assert(sizeof(u16) * BSTAGE >= sizeof(float) * T::WAVES_M * 2 * BN, "statistics scratch fits a filter stage");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = lid % p.ntiles, mt = lid / p.ntiles;
+    const int n0 = nt * BN;
+    const GatherSrc& g = p.g;
+    const int TH = geo.TH, TW = geo.TW, PW = TW + 2, PH = TH + 2;
+    const int per_img = geo.tiles_y * geo.tiles_x, nblk = g.B * per_img;
+
+    // Set-up with few integer divisions (they are ~40 instructions each, and one wavefront per SIMD has nothing to hide them behind): the
+    // sub-blocks' origins once per thread, the (row, column) of a patch pixel from a 110-entry LDS table.
+    __shared__ int s_pp[C::PIX];
+    if (tid < PIX) {
+        const int ppy = tid / PW;
+        s_pp[tid] = tid < PH * PW ? (ppy << 8) | (tid - ppy * PW) : -1;
+    }
+    int sb_base[SB], sb_y0[SB], sb_x0[SB];                       // image's first pixel index, block origin; base < 0: no such block
+#pragma unroll
+    for (int sb = 0; sb < SB; ++sb) {
+        const int blk = mt * SB + sb;
+        const int img = blk / per_img, tr = blk - img * per_img, tyi = tr / geo.tiles_x;
+        sb_base[sb] = blk < nblk ? img : -1;
+        sb_y0[sb] = tyi * TH;
+        sb_x0[sb] = (tr - tyi * geo.tiles_x) * TW;
+    }
+    {   // rows -> output pixels (row = 64 sub-block + r; r -> pixel patch_pixel(r) of the sub-block)
+        const int sbw = tid >> 6;
+        if (sbw < SB) {
+            unsigned o = OOB;
+            int img = -1, y0 = 0, x0 = 0;
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb)
+                if (sb == sbw) { img = sb_base[sb]; y0 = sb_y0[sb]; x0 = sb_x0[sb]; }
+            if (img >= 0) {
+                const int pix = patch_pixel(tid & 63);
+                const int py = pix / TW, px = pix - py * TW;
+                const int y = y0 + py, x = x0 + px;
+                if (py < TH && y < p.Hd && x < p.Wd) o = (unsigned)((img * p.Hd + y) * p.Wd + x) * (unsigned)(p.Cd * 4);
+            }
+            s_out[tid] = o;
+        }
+    }
+    __syncthreads();
+    // patch staging: thread -> (virtual patch pixel pp0 + 32 j = sub-block x patch pixel, 4 channels c4); outside the image reads as zero
+    const int c4 = tid & 7, pp0 = tid >> 3;
+    unsigned aoff[C::NJ];
+#pragma unroll
+    for (int j = 0; j < C::NJ; ++j) {
+        const int vp = pp0 + 32 * j;
+        const int sbj = vp / PIX, pp = vp - sbj * PIX;           // (division by a constant)
+        unsigned off = OOB;
+        if (vp < C::VP) {
+            int img = -1, y0 = 0, x0 = 0;
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb)
+                if (sb == sbj) { img = sb_base[sb]; y0 = sb_y0[sb]; x0 = sb_x0[sb]; }
+            const int yx = s_pp[pp];
+            if (img >= 0 && yx >= 0) {
+                const int y = y0 - 1 + (yx >> 8), x = x0 - 1 + (yx & 255);
+                if ((unsigned)y < (unsigned)g.Hs && (unsigned)x < (unsigned)g.Ws) off = (unsigned)((((img * g.Hs + y) * g.Ws + x) * g.C1 + c4 * 4) * 4);
+            }
+        }
+        aoff[j] = off;
+    }
+    const unsigned bytes1 = (unsigned)((size_t)g.B * g.Hs * g.Ws * g.C1 * 4);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1, bytes1);
+    const size_t plane_bytes = (size_t)p.Np_all * p.Kstride * 2;
+
+    const int nchunks = p.Kp / CKT;
+    auto issueA = [&](f32x4 (&ra)[C::NJ], int chunk) {
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) ra[j] = buf_load4s(rs1, aoff[j], chunk * CKT * 4);
+    };
+    auto storeA = [&](const f32x4 (&ra)[C::NJ]) {
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) {
+            const int vp = pp0 + 32 * j;
+            if (vp < C::VP) {
+                const int sb = vp / PIX, pp = vp - sb * PIX;
+                u16* const dst = Ap + sb * NS * APL + pp * LDH + (((c4 >> 1) ^ ((pp >> 2) & 3)) * 8) + (c4 & 1) * 4;
+                if constexpr (NS == 1) {
+                    *reinterpret_cast<u32x2*>(dst) = pack_bf16x4(ra[j]);
+                } else {
+                    const bf16x4 h = __builtin_convertvector(ra[j], bf16x4);
+                    const f32x4 r1 = ra[j] - __builtin_convertvector(h, f32x4);            // exact
+                    const bf16x4 m = __builtin_convertvector(r1, bf16x4);
+                    const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);               // exact
+                    *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, h);
+                    *reinterpret_cast<u32x2*>(dst + APL) = __builtin_bit_cast(u32x2, m);
+                    *reinterpret_cast<u32x2*>(dst + 2 * APL) = pack_bf16x4(r2);
+                }
+            }
+        }
+    };
+    // Filter tiles of stage s = (chunk, ky) by LDS-DMA: 3 NS (tap, plane) tiles of BN rows x 64 bytes = 3 NS BN / 16 pieces of 1 KiB, wavefront
+    // w issues pieces w, w + 4, ...  Piece q: tile q / (BN / 16), rows 16 (q % (BN / 16)) ..; lane -> row + (lane >> 2), LDS slot lane & 3, which
+    // holds the logical slot (lane & 3) ^ ((row >> 2) & 3) of that row.  Rows past the launch's outputs re-read its last row (results dropped).
+    const int lrow = lane >> 2, lsp = lane & 3;
+    auto issueB = [&](int s) {
+        const int chunk = s / 3, ky = s - chunk * 3;
+        u16* const ring = Bs + (s & 1) * BSTAGE;
+        constexpr int PPT = BN / 16, NPIECE = 3 * NS * PPT;          // pieces per tile, per stage
+#pragma unroll
+        for (int i = 0; i < (NPIECE + 3) / 4; ++i) {
+            const int q = wave + 4 * i;
+            if (NPIECE % 4 != 0 && q >= NPIECE) break;
+            const int tp = q / PPT, kx = tp / NS, pl = tp - kx * NS;
+            const int row = 16 * (q % PPT) + lrow;
+            const int slot = lsp ^ ((row >> 2) & 3);
+            int n = n0 + row;
+            if (n >= p.n_count) n = p.n_count - 1;
+            const char* src = reinterpret_cast<const char*>(w16) + pl * plane_bytes +
+                              ((size_t)(p.n_begin + n) * p.Kstride + (size_t)((ky * 3 + kx) * p.Kp + chunk * CKT + slot * 8)) * 2;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ring + tp * BPL + 16 * (q % PPT) * LDH), 16, 0, 0);
+        }
+    };
+
+    const int wm0 = wave * (BM / 4), wn0 = 0;
+    typename T::AccT acc[TM][TN], mid[NS > 1 ? TM : 1][NS > 1 ? TN : 1], low[NS > 1 ? TM : 1][NS > 1 ? TN : 1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (NS > 1) { mid[i][j][r] = 0.f; low[i][j][r] = 0.f; }
+            }
+    const int frow = lane & 31;
+    // this lane's A rows = output pixels of its sub-block -> patch pixel (py + dy, px + dx), dy / dx = the tap (mirrored for the data gradient)
+    const u16* abase[TM];
+    int prow[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int R = wm0 + 32 * i + frow;
+        const int sb = R >> 6;
+        const int pix = patch_pixel(R & 63);
+        const int py = pix / TW, px = pix - py * TW;
+        prow[i] = py < TH ? py * PW + px : 0;                    // rows past the block multiply pixel 0 (their results are dropped)
+        abase[i] = Ap + sb * NS * APL;
+    }
+    const int fslot = lane >> 5;                                  // which 16-byte half of a k-step this lane holds
+    int boffs[TN][2];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int brow = 32 * j + frow;
+        boffs[j][0] = brow * LDH + ((fslot ^ ((brow >> 2) & 3)) * 8);
+        boffs[j][1] = brow * LDH + (((2 + fslot) ^ ((brow >> 2) & 3)) * 8);
+    }
+    const bool fwd = g.sign > 0;
+    auto compute = [&](int ky, const u16* ring) {
+        const int rsh = (fwd ? ky : 2 - ky) * PW + (fwd ? 0 : 2);                          // patch row shift of tap (ky, 0); tap kx is dxr rows further
+        const int dxr = fwd ? 1 : -1;
+        bf16x8 fa[2][TM][NS], fb[2][TN][NS];
+        auto load = [&](int i, bf16x8 (&a)[TM][NS], bf16x8 (&b)[TN][NS]) {
+            const int kx = i >> 1, ks = i & 1;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const u16* const bp = ring + kx * NS * BPL + boffs[j][ks];
+#pragma unroll
+                for (int q = 0; q < NS; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(bp + q * BPL);
+            }
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const int row = prow[t] + rsh + kx * dxr;
+                const u16* const ap = abase[t] + row * LDH + (((2 * ks + fslot) ^ ((row >> 2) & 3)) * 8);
+#pragma unroll
+                for (int q = 0; q < NS; ++q) a[t][q] = *reinterpret_cast<const bf16x8*>(ap + q * APL);
+            }
+        };
+        load(0, fa[0], fb[0]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i + 1 < 6) load(i + 1, fa[(i + 1) & 1], fb[(i + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bf16x8(&a)[NS] = fa[i & 1][t];
+                    const bf16x8(&b)[NS] = fb[i & 1][j];
+                    if constexpr (NS == 1) {
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[t][j], 0, 0, 0);
+                    } else {
+                        low[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], low[t][j], 0, 0, 0);
+                        mid[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], mid[t][j], 0, 0, 0);
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[t][j], 0, 0, 0);
+                        low[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], low[t][j], 0, 0, 0);
+                        mid[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], mid[t][j], 0, 0, 0);
+                        low[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], low[t][j], 0, 0, 0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    f32x4 ra[C::NJ];
+    const int total = nchunks * 3;
+    issueA(ra, 0);
+    issueB(0);
+    storeA(ra);
+    __syncthreads();                                             // (with an LDS-DMA in flight the compiler drains vmcnt here: stage 0 has landed)
+    int ky = 0, chunk = 0;
+    constexpr int diag = MCAV_PATCH2_DIAG;
+    for (int s = 0; s < total; ++s) {
+        const bool more = chunk + 1 < nchunks;
+        if (s + 1 < total && !(diag & 1)) issueB(s + 1);         // into the ring slot stage s - 1 was read from (every wavefront is past its barrier)
+        if (ky == 0 && more && !(diag & 8)) issueA(ra, chunk + 1);
+        if (!(diag & 2)) compute(ky, Bs + (s & 1) * BSTAGE);
+        __syncthreads();                                         // stage s + 1 has landed; everyone is done with stage s and (ky == 2) with the patch
+        if (ky == 2 && more && !(diag & 8)) {
+            storeA(ra);
+            __syncthreads();
+        }
+        if (++ky == 3) { ky = 0; ++chunk; }
+    }
+    if (diag & 4) return;
+    if constexpr (NS > 1) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[t][j] += mid[t][j] + low[t][j];
+    }
+    igemm_epilogue_lean<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
+}
+
 // ------------------------------------------------------------------------------------------------ the same on the fp32 MFMA (mma = 0)
 // conv3x3_patch_kernel's structure with fp32 operands and v_mfma_f32_32x32x2_f32: the default (fp32) path of the trunk's 3x3 stride-1
 // zero-padded convolutions and their data gradients.  The table-driven kernel fetches the A operand once per tap through L2; with those
@@ -826,6 +1099,45 @@ static bool patch_plan(const mcav_igemm_desc* d, PatchGeo& geo, bool f32 = false
     // plain bf16 on few blocks (the 6x20 maps): the table-driven 32x64 tiles are faster (0.043 against 0.055 ms on 512 -> 512)
     if (d->mma == 1 && (long)d->B * geo.tiles_y * geo.tiles_x * ((d->n_count + 63) / 64) < 1024) return false;
     return true;
+}
+
+// Second form (conv3x3_patch2_kernel): SB = 4 or 2 sub-blocks of 64 pixels per workgroup, one workgroup per CU; 0 = not this form.  The
+// choice is a count of rounds: a launch runs ceil(workgroups / CUs) rounds of SB units of work each, and the fewer sub-blocks win a tie only
+// when they save a round (the filter stream per FLOP doubles with them).  A workgroup's sub-blocks must belong to one statistics group.
+static int patch2_plan(const mcav_igemm_desc* d, PatchGeo& geo, int& bn) {
+    // OFF by default: measured level with or behind the first kernel on every trunk shape (profiles/r04_patch2_forms.txt).
+    // mcav_igemm_desc.tile bit 14 selects it (bit 15: its 128 x 32 two-workgroups-per-CU configuration): the parity tests; MCAV_PATCH2=1 in a
+    // -DMCAV_TUNE_ENV build: experiments.
+    static const int enabled = MCAV_KNOB_INT("MCAV_PATCH2", 0);
+    static const int force_sb = MCAV_KNOB_INT("MCAV_PATCH2_SB", 0);
+    static const int force_bn = MCAV_KNOB_INT("MCAV_PATCH2_BN", 0);
+    if (!d || d->mma < 2) return 0;                                   // (the split form; plain bf16 keeps the first kernel)
+    if (!enabled && !((d->tile >> 14) & 3)) return 0;
+    PatchGeo g1;
+    if (!patch_plan(d, g1)) return 0;
+    int th, tw;
+    patch_block(d->Hd, d->Wd, 64, PatchCfg<1>::PIX, th, tw);
+    geo.TH = th; geo.TW = tw; geo.tmb = 1;
+    geo.tiles_y = (d->Hd + th - 1) / th;
+    geo.tiles_x = (d->Wd + tw - 1) / tw;
+    const long per_img = (long)geo.tiles_y * geo.tiles_x, nblk = d->B * per_img, ntiles = (d->n_count + 63) / 64;
+    const int groups = (d->stats && d->groups > 1) ? d->groups : 1;
+    static const int cus = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        const int n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        (void)hipGetLastError();
+        return n;
+    }();
+    auto fits = [&](int sb) { return d->B % groups == 0 && ((d->B / groups) * per_img) % sb == 0; };
+    auto cost = [&](int sb) { const long wgs = ((nblk + sb - 1) / sb) * ntiles; return ((wgs + cus - 1) / cus) * sb; };
+    int sb = 0;
+    if (fits(4)) sb = 4;
+    if (fits(2) && (sb == 0 || cost(2) < cost(4))) sb = 2;
+    if ((force_sb == 2 || force_sb == 4) && fits(force_sb)) sb = force_sb;
+    bn = 64;
+    if ((force_bn == 32 || ((d->tile >> 15) & 1)) && fits(2)) { sb = 2; bn = 32; }
+    return sb;
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -1180,6 +1492,30 @@ int mcav_bf16_igemm(const mcav_igemm_desc* d, hipStream_t s) {
     int tile;
     // (past this point the caller may have put the bf16 copy into d->w as well: never fall through to the fp32 kernels)
     PatchGeo geo;
+    int bn2 = 64;
+    if (const int sb = patch2_plan(d, geo, bn2)) {
+        dd.tile = 10;
+        if (!fill_params(&dd, p, tile) || p.upm) return MCAV_E_INVALID;
+        if ((long)d->Np * p.Kstride * 2 * 3 >= 0x7fffffffL) return MCAV_E_INVALID;
+        const long nblk = (long)d->B * geo.tiles_y * geo.tiles_x;
+        p.mtiles = (int)((nblk + sb - 1) / sb);                      // rows of the statistics slab = workgroup rows, image-major
+        p.ntiles = (p.n_count + bn2 - 1) / bn2;
+        static const bool allowed = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch2_kernel<3, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)patch2_lds_bytes<3, 4, 64>()) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch2_kernel<3, 2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)patch2_lds_bytes<3, 2, 64>()) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch2_kernel<3, 2, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)patch2_lds_bytes<3, 2, 32>()) == hipSuccess;
+        }();
+        if (!allowed) return MCAV_E_LAUNCH;
+        const int grid = p.mtiles * p.ntiles;
+        const u16* w16 = reinterpret_cast<const u16*>(d->w16);
+        if (bn2 == 32) timed_launch(conv3x3_patch2_kernel<3, 2, 32>, grid, dim3(256), patch2_lds_bytes<3, 2, 32>(), s, p, w16, geo);
+        else if (sb == 4) timed_launch(conv3x3_patch2_kernel<3, 4, 64>, grid, dim3(256), patch2_lds_bytes<3, 4, 64>(), s, p, w16, geo);
+        else timed_launch(conv3x3_patch2_kernel<3, 2, 64>, grid, dim3(256), patch2_lds_bytes<3, 2, 64>(), s, p, w16, geo);
+        return launch_status();
+    }
     if (patch_plan(d, geo)) {
         dd.tile = 10;
         if (!fill_params(&dd, p, tile) || p.upm) return MCAV_E_INVALID;
@@ -1236,6 +1572,8 @@ int mcav_bf16_igemm_mtiles(const mcav_igemm_desc* d) {
     const int bt = bf16_tile_for(d, &refl);
     if (!bt) return 0;
     PatchGeo geo;
+    int bn2 = 64;
+    if (const int sb = patch2_plan(d, geo, bn2)) return (int)(((long)d->B * geo.tiles_y * geo.tiles_x + sb - 1) / sb);
     if (patch_plan(d, geo)) return d->B * geo.tiles_y * geo.tiles_x;
     mcav_igemm_desc dd = *d;
     dd.tile = bt >> 1;

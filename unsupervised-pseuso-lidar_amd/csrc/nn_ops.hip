@@ -100,6 +100,72 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* stats, int
     }
 }
 
+// Stage 1 and the finalize in ONE launch (round 4: 15 launches fewer per step).  Every block leaves its slice's partial sums in `part`
+// (doubles, agent-scope stores: the hand-off protocol of mcav_common.h); a ticket per 64-channel column names the LAST block of that column,
+// which sums the slices in index order (bit-reproducible whichever block finishes) for every group in turn -- running statistics see pass
+// 0, then pass 1 -- and leaves the ticket at zero for the next launch on this workspace.
+__global__ __launch_bounds__(256) void bn_partial_finalize_kernel(const float* stats, int mtiles, int C, int per_slice, double* part, unsigned* tickets,
+                                                                  double count, const float* gamma, const float* beta, float eps, float momentum,
+                                                                  float* running_mean, float* running_var, float* scale, float* shift,
+                                                                  float* save_mean, float* save_invstd) {
+    __shared__ double s1[4][64], s2[4][64];
+    __shared__ int s_last;
+    const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const int slice = blockIdx.y, g = blockIdx.z, nsl = gridDim.y, groups = gridDim.z;
+    const float* st = stats + (size_t)g * mtiles * 2 * C;
+    const int t0 = slice * per_slice, t1 = min(mtiles, t0 + per_slice);
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int t = t0 + tl; t < t1; t += 4) {
+            a += (double)st[((size_t)t * 2 + 0) * C + c];
+            b += (double)st[((size_t)t * 2 + 1) * C + c];
+        }
+    s1[tl][cl] = a; s2[tl][cl] = b;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+        for (int k = 1; k < 4; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        double* o = part + ((size_t)g * nsl + slice) * 2 * C;
+        handoff_store(o + c, a);
+        handoff_store(o + C + c, b);
+    }
+    handoff_release();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = handoff_ticket(&tickets[blockIdx.x]) == (unsigned)(nsl * groups - 1);
+    __syncthreads();
+    if (!s_last) return;
+    for (int gg = 0; gg < groups; ++gg) {
+        a = 0.0; b = 0.0;
+        if (c < C)
+            for (int sl = tl; sl < nsl; sl += 4) {
+                const double* o = part + ((size_t)gg * nsl + sl) * 2 * C;
+                a += handoff_load(o + c);
+                b += handoff_load(o + C + c);
+            }
+        __syncthreads();
+        s1[tl][cl] = a; s2[tl][cl] = b;
+        __syncthreads();
+        if (tl == 0 && c < C) {
+            a = ((s1[0][cl] + s1[1][cl]) + s1[2][cl]) + s1[3][cl];
+            b = ((s2[0][cl] + s2[1][cl]) + s2[2][cl]) + s2[3][cl];
+            const double mean = a / count;
+            double var = b / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = gamma[c] * invstd;
+            scale[gg * C + c] = sc;
+            shift[gg * C + c] = beta[c] - (float)mean * sc;
+            save_mean[gg * C + c] = (float)mean;
+            save_invstd[gg * C + c] = invstd;
+            if (running_mean) {
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+                running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+        }
+    }
+    if (threadIdx.x == 0) handoff_store(&tickets[blockIdx.x], 0u);
+}
+
 constexpr int FIN_SL = 32;             // slice lanes of the finalize kernels: 32 channels x 32 slices = 1024 threads (short dependent-load chains)
 
 template <class TIn>
@@ -455,7 +521,9 @@ MCAV_EXPORT int mcav_nhwc_to_nchw(const float* src, int B, int C, int H, int W, 
 MCAV_EXPORT size_t mcav_bn_finalize_workspace_bytes(int mtiles, int C, int groups) {
     if (groups < 1) groups = 1;
     if (mtiles <= BNF_DIRECT || C <= 0) return 0;
-    return align_up(sizeof(double) * 2 * (size_t)C * BNF_SLICES * groups, 256);
+    // the slices' partial sums + one completion ticket per 64-channel column (the caller zero-fills a workspace when it allocates it; the
+    // kernel leaves the tickets at zero)
+    return align_up(sizeof(double) * 2 * (size_t)C * BNF_SLICES * groups, 256) + align_up(sizeof(unsigned) * ((size_t)(C + 63) / 64), 256);
 }
 
 MCAV_EXPORT int mcav_bn_finalize(const float* stats, int mtiles, int C, double count, const float* gamma, const float* beta, float eps, float momentum,
@@ -475,9 +543,9 @@ MCAV_EXPORT int mcav_bn_finalize(const float* stats, int mtiles, int C, double c
     if (per_slice < 8) per_slice = 8;
     const int slices = (mtiles + per_slice - 1) / per_slice;
     double* part = reinterpret_cast<double*>(workspace);
-    bn_partial_kernel<<<dim3((C + 63) / 64, slices, groups), 256, 0, s>>>(stats, mtiles, C, per_slice, part);
-    bn_finalize_kernel<double><<<(C + 31) / 32, 32 * FIN_SL, 0, s>>>(part, slices, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale,
-                                                             shift, save_mean, save_invstd, groups);
+    unsigned* tickets = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + align_up(sizeof(double) * 2 * (size_t)C * BNF_SLICES * groups, 256));
+    bn_partial_finalize_kernel<<<dim3((C + 63) / 64, slices, groups), 256, 0, s>>>(stats, mtiles, C, per_slice, part, tickets, count, gamma, beta, eps, momentum,
+                                                                                   running_mean, running_var, scale, shift, save_mean, save_invstd);
     return launch_status();
 }
 

@@ -15,6 +15,14 @@ def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def parallel():
+    """True when the collective path runs: more than one rank -- or MCAV_DP_FORCE=1 with an initialised 1-rank group (the RCCL dry run on a
+    one-GPU box: communicator, streams and Work.wait() ordering exercised, the sums are the identity)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("MCAV_DP_FORCE", "0") == "1"
+
+
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -22,7 +30,7 @@ def rank():
 def init_from_env(backend=None):
     """torchrun-style env (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR/PORT).  backend 'nccl' is RCCL on ROCm."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws <= 1 or dist.is_initialized():
+    if (ws <= 1 and os.environ.get("MCAV_DP_FORCE", "0") != "1") or dist.is_initialized():
         return rank(), world()
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -37,7 +45,7 @@ def init_from_env(backend=None):
 
 
 def broadcast_parameters(arena, src=0):
-    if world() > 1:
+    if parallel():
         dist.broadcast(arena.flat, src)
         arena.bump()
 
@@ -72,6 +80,7 @@ class GradSync:
         self.done = []          # [lo, hi) ranges already handed to a collective this step
         self.sizes = []         # bytes of each collective issued this step, in issue order
         self.last_buckets = []  # ... of the last finished step (bench.py reports it)
+        self.comm = None        # communication stream of ready_range()
 
     def span(self, params):
         a = self.arena
@@ -84,7 +93,7 @@ class GradSync:
         return a.offsets[idx[0]], hi
 
     def ready(self, params):
-        if world() <= 1:
+        if not parallel():
             return
         r = self.span(params)
         if r is None or any(not (r[1] <= lo or hi <= r[0]) for lo, hi in self.done):
@@ -101,9 +110,28 @@ class GradSync:
         self.done.append(r)
         self.sizes.append(4 * (r[1] - r[0]))
 
+    def ready_range(self, r, event=None):
+        """All-reduce the arena range r = [lo, hi) asynchronously on the communication stream.  event: an mcav external event (mcav/graph.py)
+        that a REPLAYING hipGraph signals when the gradients of this range are final -- the communication stream waits for it, so the
+        collective starts while the rest of the graph's backward pass is still running (replay and overlap together: BASELINE.json configs[4])."""
+        if not parallel() or r is None or any(not (r[1] <= lo or hi <= r[0]) for lo, hi in self.done):
+            return
+        from . import lib as L
+        buf = self.arena.gflat[r[0]:r[1]]
+        if self.comm is None or self.comm.device != buf.device:
+            self.comm = torch.cuda.Stream(device=buf.device)
+        if event is not None:
+            L.check(L.lib().mcav_stream_wait_event(L.c_p(self.comm.cuda_stream), event), "mcav_stream_wait_event")
+        else:
+            self.comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm):
+            self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+        self.done.append(r)
+        self.sizes.append(4 * (r[1] - r[0]))
+
     def finish(self):
         """Call after backward() has returned (all streams joined).  Reduces the remaining ranges, then waits for all."""
-        if world() > 1:
+        if parallel():
             pos = 0
             step = remainder_bucket_elems()
             for lo, hi in sorted(self.done) + [(self.arena.numel, self.arena.numel)]:
@@ -127,7 +155,7 @@ def enable_overlap(arena):
     from . import nn as N
     gs = GradSync(arena)
     _SYNC[id(arena)] = gs
-    N.GRADS_READY = gs.ready if world() > 1 else None
+    N.GRADS_READY = gs.ready if parallel() else None
     return gs
 
 
@@ -135,7 +163,7 @@ def allreduce_gradients(arena):
     """Sum the gradient arena over ranks.  Returns the scale Adam must apply (1/world).
     One collective, or -- after enable_overlap(arena) -- the remainder of the bucketed, backward-overlapped reduction."""
     w = world()
-    if w > 1:
+    if parallel():
         gs = _SYNC.get(id(arena))
         if gs is not None and gs.arena is arena:
             gs.finish()

@@ -90,6 +90,10 @@ L.register({
     "mcav_upsample_nearest2x_bwd": (c_i, [c_p, c_sz, c_i, c_i, c_p, c_p]),
     "mcav_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_sz, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
     "mcav_adam_step_dev": (c_i, [c_p, c_p, c_p, c_p, c_sz, c_f, c_f, c_f, c_p, c_p]),
+    "mcav_event_create": (c_i, [ctypes.POINTER(c_p)]),
+    "mcav_event_destroy": (c_i, [c_p]),
+    "mcav_event_record_external": (c_i, [c_p, c_p]),
+    "mcav_stream_wait_event": (c_i, [c_p, c_p]),
     "mcav_kernel_timer_begin": (c_i, []),
     "mcav_kernel_timer_count": (c_i, []),
     "mcav_kernel_timer_end": (c_i, [c_p, c_i]),
@@ -819,7 +823,7 @@ def bn_train_coeffs(bn, slab, count, groups=1):
     h = L.lib()
     mtiles = slab.shape[0] // groups
     nbytes = h.mcav_bn_finalize_workspace_bytes(mtiles, C, groups)
-    ws = L.workspace(nbytes, slab.device, "bn_fin") if nbytes else None
+    ws = L.workspace(nbytes, slab.device, "bn_fin", zero=True) if nbytes else None      # (holds the finalize kernel's completion tickets: zero at allocation)
     L.check(h.mcav_bn_finalize(P(slab), mtiles, C, float(count), P(bn.weight), P(bn.bias), bn.eps, bn.momentum,
                                P(bn.running_mean), P(bn.running_var), P(st.scale), P(st.shift), P(st.mean), P(st.invstd), groups,
                                P(ws), ws.numel() if ws is not None else 0, L.stream()), "mcav_bn_finalize")

@@ -153,7 +153,8 @@ class Trainer:
 
     def _graphed_step(self, samples):
         """action.hipgraph: the same step replayed as one captured hipGraph per input shape (mcav/graph.py).  On one rank the Adam update is
-        inside the graph; with several ranks the all-reduce and Adam follow the replay eagerly."""
+        inside the graph; with several ranks the bucketed all-reduce runs BESIDE the replay (each bucket behind an external event node of
+        the graph) and Adam follows eagerly."""
         dev = self.device
         tgt = samples['tgt'].to(dev, non_blocking=True)
         ref_imgs = [img.to(dev, non_blocking=True) for img in samples['ref_imgs']]
@@ -167,10 +168,10 @@ class Trainer:
                 sum(loss).backward()
                 return tuple(loss)
             buffers = list(self.depth_model.buffers()) + list(self.pose_model.buffers())
-            self._graphs = StepGraphs(fwd_bwd, self.model_optimizer, capture_adam=self.world == 1, buffers=buffers)
+            self._graphs = StepGraphs(fwd_bwd, self.model_optimizer, capture_adam=not mdist.parallel(), buffers=buffers)
         self.model_optimizer.grad_scale = 1.0 / self.world
         self.loss = list(self._graphs(tgt, ref_imgs[0], ref_imgs[1], K))
-        if self.world > 1:
+        if mdist.parallel():      # the buckets' collectives are already in flight behind the replaying graph (mcav/graph.py); remainder, wait, Adam
             self.model_optimizer.grad_scale = mdist.allreduce_gradients(self.model_optimizer.arena())
             self.model_optimizer.step()
         self.step += 1
