@@ -170,7 +170,9 @@ int mcav_pack_weights(const float* w_oihw, int Cout, int Cin, int kh, int kw, in
 /* The same for many filters in ONE launch.  items_dev: device array of nitems records
  *   { const float* src; float* dst; int Cout, Cin, taps, transposed, Np, Kp, Kstride, first_block; }   (48 bytes each)
  * where Kstride = taps * Kp rounded up to 16 and first_block is the running sum of mcav_pack_weights_blocks(...) over the
- * preceding records; nblocks = that sum over all records. */
+ * preceding records; nblocks = that sum over all records.  transposed bits: 0 = the data-gradient layout, 1 = bf16 destination, 2 = three
+ * bf16 planes h, m, l; bit 3 (8) = the merged-tap forward copy of mcav_pack_weights_upmerge and bit 4 (16) = the adjoint copy of
+ * mcav_pack_weights_upmerge_adj, both with C1 in `taps` (Np, Kp as in those entry points; Kstride unused). */
 int mcav_pack_weights_multi(const void* items_dev, int nitems, int nblocks, void* stream);
 /* A record whose `transposed` has bit 1 set (2 or 3) writes its packed copy as bf16 (same layout, 2-byte elements): the filter copies
  * of the bf16 MFMA kernels, re-derived from the fp32 master weights after every optimiser step in the same launch.  Bit 2 (4 or 5): as

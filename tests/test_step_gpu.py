@@ -372,6 +372,32 @@ def test_full_size_step_is_bit_reproducible_and_pair_equals_separate():
     hip_d.train()
 
 
+def test_full_size_forward_and_losses_vs_oracle_on_the_default_mode():
+    """BASELINE.json configs[1]'s own shape (batch 12, 192x640, ResNet-18 + PoseNet) on the DEFAULT compute mode (fp32 results; the trunk's 3x3
+    stride-1 convolutions on split operands) against the CPU oracle's forward on identical inputs and weights: depth
+    maps of BOTH passes within north_star's 1e-3 max-relative with AbsRel < 1e-4, poses to 1e-4, both loss scalars to 1e-4 relative.  (The
+    oracle's forward of this size takes ~15 s of host time; its backward is what the smaller step cases and the float64 arbiter cover.)"""
+    from losses import Losses
+    from oracle.step import process_batch, synthetic_batch
+    hip_d, hip_p, ref_d, ref_p = build_pair()
+    s = synthetic_batch(12, 192, 640, seed=23)
+    with torch.no_grad():
+        (rdisps, rposes), rloss = process_batch(ref_d, ref_p, s)
+    tgt, refs, K = s["tgt"].to(DEV), [r.to(DEV) for r in s["ref_imgs"]], s["intrinsics"].to(DEV)
+    with torch.no_grad():
+        disps = list(hip_d.forward_pair(tgt, refs[0]))
+        poses = hip_p(tgt, refs)
+        loss = Losses().forward(tgt, refs, disps, poses, K, None)
+    for got, want in zip(disps, rdisps):
+        dg, dw = 1 / (10 * got[0].cpu().double() + 0.01), 1 / (10 * want[0].double() + 0.01)
+        rel = (dg - dw).abs() / dw
+        print("12x192x640 depth vs oracle: max-rel %.3e AbsRel %.3e" % (float(rel.max()), float(rel.mean())))
+        assert float(rel.max()) < 1e-3 and float(rel.mean()) < 1e-4
+    assert rel_err(poses, rposes) < 1e-3
+    for a, b in zip(loss, rloss):
+        assert abs(float(a) - float(b)) < 1e-4 * abs(float(b)), (float(a), float(b))
+
+
 def test_trainer_validate_runs():
     """The validation loop of the reference (trainer.py:315-337, never called there and broken in compute_errors) runs on the GPU metrics kernel."""
     import yaml

@@ -14,6 +14,8 @@ python3 $ROOT/tools/rocpd_stats.py $(ls $OUT/stats/*/*_results.db | head -1) $OU
 echo stats done
 rocprofv3 --kernel-trace --stats -d $OUT/stats_serial -- python3 $B --steps 10 --warmup 3 --serial > $OUT/stats_serial.log 2>&1
 python3 $ROOT/tools/rocpd_stats.py $(ls $OUT/stats_serial/*/*_results.db | head -1) $OUT/kernel_stats_serial.csv
+python3 $ROOT/tools/rocpd_sequence.py $(ls $OUT/stats_serial/*/*_results.db | head -1) > $OUT/step_sequence.txt
+python3 $ROOT/tools/rocpd_sequence.py $(ls $OUT/stats_serial/*/*_results.db | head -1) copyBuffer > $OUT/step_copies.txt
 echo serial stats done
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $B --steps 2 --warmup 1 > $OUT/fetch.log 2>&1
 echo fetch done
@@ -27,7 +29,7 @@ echo ssim pmc done
 rocprofv3 --kernel-trace --stats -d $OUT/stats_bf16 -- python3 $B --steps 10 --warmup 3 --serial --dtype bf16 > $OUT/stats_bf16.log 2>&1
 python3 $ROOT/tools/rocpd_stats.py $(ls $OUT/stats_bf16/*/*_results.db | head -1) $OUT/kernel_stats_serial_bf16.csv
 echo bf16 stats done
-rocprofv3 --kernel-trace --stats -d $OUT/stats_split -- python3 $B --steps 10 --warmup 3 --serial --dtype fp32-split > $OUT/stats_split.log 2>&1
-python3 $ROOT/tools/rocpd_stats.py $(ls $OUT/stats_split/*/*_results.db | head -1) $OUT/kernel_stats_serial_split.csv
-echo split stats done
+rocprofv3 --kernel-trace --stats -d $OUT/stats_split -- python3 $B --steps 10 --warmup 3 --serial --dtype fp32-mfma > $OUT/stats_split.log 2>&1
+python3 $ROOT/tools/rocpd_stats.py $(ls $OUT/stats_split/*/*_results.db | head -1) $OUT/kernel_stats_serial_fp32_mfma.csv
+echo fp32-mfma stats done
 rm -rf $OUT/stats $OUT/stats_serial $OUT/fetch $OUT/write $OUT/fetch_ssim $OUT/write_ssim $OUT/stats_bf16 $OUT/stats_split

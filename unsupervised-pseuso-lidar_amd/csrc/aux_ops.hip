@@ -291,10 +291,39 @@ MCAV_EXPORT int mcav_event_record_external(void* event, void* stream) {
     if (!event) return MCAV_E_INVALID;
     hipStream_t s = as_stream(stream);
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return MCAV_E_LAUNCH; }
-    const hipError_t e = st == hipStreamCaptureStatusActive ? hipEventRecordWithFlags(reinterpret_cast<hipEvent_t>(event), s, hipEventRecordExternal)
-                                                           : hipEventRecord(reinterpret_cast<hipEvent_t>(event), s);
-    if (e != hipSuccess) { (void)hipGetLastError(); return MCAV_E_LAUNCH; }
+    hipError_t e = hipStreamIsCapturing(s, &st);
+    if (e != hipSuccess) {
+        fprintf(stderr, "mcav_event_record_external: hipStreamIsCapturing: %s\n", hipGetErrorName(e));
+        (void)hipGetLastError();
+        return -(2000 + (int)e);
+    }
+    if (st != hipStreamCaptureStatusActive) {
+        e = hipEventRecord(reinterpret_cast<hipEvent_t>(event), s);
+        if (e != hipSuccess) { (void)hipGetLastError(); return -(1000 + (int)e); }
+        return MCAV_OK;
+    }
+    // Under capture: the node is added to the graph being captured explicitly -- an event-record node behind the stream's current dependency
+    // set, which then becomes the set.  (hipEventRecordWithFlags(..., hipEventRecordExternal) on the capturing stream is the short spelling;
+    // this ROCm's runtime answers it with hipErrorInvalidValue under torch's capture, measured round 4, so it is only the fallback.)
+    unsigned long long id = 0;
+    hipGraph_t graph = nullptr;
+    const hipGraphNode_t* deps = nullptr;
+    size_t ndeps = 0;
+    e = hipStreamGetCaptureInfo_v2(s, &st, &id, &graph, &deps, &ndeps);
+    if (e == hipSuccess && graph) {
+        hipGraphNode_t node = nullptr;
+        e = hipGraphAddEventRecordNode(&node, graph, deps, ndeps, reinterpret_cast<hipEvent_t>(event));
+        if (e == hipSuccess) e = hipStreamUpdateCaptureDependencies(s, &node, 1, hipStreamSetCaptureDependencies);
+        if (e == hipSuccess) return MCAV_OK;
+        fprintf(stderr, "mcav_event_record_external: explicit event-record node: %s\n", hipGetErrorName(e));
+    }
+    (void)hipGetLastError();
+    e = hipEventRecordWithFlags(reinterpret_cast<hipEvent_t>(event), s, hipEventRecordExternal);
+    if (e != hipSuccess) {
+        fprintf(stderr, "mcav_event_record_external: hipEventRecordWithFlags(external): %s\n", hipGetErrorName(e));
+        (void)hipGetLastError();
+        return -(1000 + (int)e);      // (-1000 - hipError_t: the binding prints the number)
+    }
     return MCAV_OK;
 }
 

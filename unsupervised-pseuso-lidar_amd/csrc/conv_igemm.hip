@@ -1640,7 +1640,51 @@ constexpr int PK_CO = 64;
 
 __host__ __device__ inline int pack_ci_tile(int taps) { const int t = 79 / taps; return t < 1 ? 1 : (t > 8 ? 8 : t); }      // 64 x (tile x taps + 1) <= PK_LDS
 
+// Merged-tap copies of the decoder's upsample convolutions (mcav_pack_weights_upmerge / _upmerge_adj) as items of the same launch (round 4:
+// ten small launches fewer per step): PackItem.transposed bit 3 = the forward copy [4 classes][Np][4 merged taps][C1], bit 4 = the adjoint copy
+// [Np = c1][16 taps (u, v)][Kp = co]; PackItem.taps carries C1; a block handles PK_MERGE consecutive elements.
+constexpr int PK_MERGE = 2048;
+
+__device__ __forceinline__ float upmerge_elem(const float* w, int Cout, int Cin, int C1, int Np, size_t e) {
+    const int c = (int)(e % C1);
+    const int mt = (int)((e / C1) % 4), n = (int)((e / ((size_t)C1 * 4)) % Np), cls = (int)(e / ((size_t)C1 * 4 * Np));
+    const int py = cls >> 1, px = cls & 1, a = mt >> 1, b = mt & 1;
+    float sum = 0.f;
+    if (n < Cout) {
+        const float* wc = w + ((size_t)n * Cin + c) * 9;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const bool iny = py == 0 ? (a == 0 ? ky == 0 : ky >= 1) : (a == 0 ? ky <= 1 : ky == 2);
+                const bool inx = px == 0 ? (b == 0 ? kx == 0 : kx >= 1) : (b == 0 ? kx <= 1 : kx == 2);
+                if (iny && inx) sum += wc[ky * 3 + kx];
+            }
+    }
+    return sum;
+}
+
+// V[u][v][c1][co] = sum of w[co][c1][ky][kx] over ky in Sy(u), kx in Sy(v); Sy(0) = {2}, Sy(1) = {1,2}, Sy(2) = {0,1}, Sy(3) = {0}.
+__device__ __forceinline__ float upmerge_adj_elem(const float* w, int Cout, int Cin, int C1, int Kp, size_t e) {
+    const int k = (int)(e % Kp), tap = (int)((e / Kp) % 16), n = (int)(e / ((size_t)Kp * 16));
+    const int u = tap >> 2, v = tap & 3;
+    float sum = 0.f;
+    if (n < C1 && k < Cout) {
+        const float* wc = w + ((size_t)k * Cin + n) * 9;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const bool iny = u == 0 ? ky == 2 : (u == 1 ? ky >= 1 : (u == 2 ? ky <= 1 : ky == 0));
+                const bool inx = v == 0 ? kx == 2 : (v == 1 ? kx >= 1 : (v == 2 ? kx <= 1 : kx == 0));
+                if (iny && inx) sum += wc[ky * 3 + kx];
+            }
+    }
+    return sum;
+}
+
+__host__ __device__ inline size_t pack_merge_total(int transposed, int c1, int Np, int Kp) {
+    return (transposed & 16) ? (size_t)Np * 16 * Kp : (size_t)4 * Np * 4 * c1;
+}
+
 __host__ __device__ inline int pack_blocks(int transposed, int taps, int Np, int Kp) {
+    if (transposed & 24) return (int)((pack_merge_total(transposed, taps, Np, Kp) + PK_MERGE - 1) / PK_MERGE);
     if (!(transposed & 1)) return Np;
     const int ct = pack_ci_tile(taps);
     return ((Np + ct - 1) / ct) * ((Kp + PK_CO - 1) / PK_CO);
@@ -1654,6 +1698,17 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackItem*
         if (items[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     PackItem it = items[lo];
+    if (it.transposed & 24) {                           // a merged-tap copy: taps = C1
+        const size_t total = pack_merge_total(it.transposed, it.taps, it.Np, it.Kp);
+        const size_t e0 = (size_t)(blockIdx.x - it.first_block) * PK_MERGE;
+        for (int k = 0; k < PK_MERGE / 256; ++k) {
+            const size_t e = e0 + (size_t)k * 256 + threadIdx.x;
+            if (e < total)
+                it.dst[e] = (it.transposed & 16) ? upmerge_adj_elem(it.src, it.Cout, it.Cin, it.taps, it.Kp, e)
+                                                 : upmerge_elem(it.src, it.Cout, it.Cin, it.taps, it.Np, e);
+        }
+        return;
+    }
     const bool to_bf16 = (it.transposed & 6) != 0;      // bit 1: the destination holds bf16 (the filter copies of the bf16 MFMA kernels)
     const bool planes = (it.transposed & 4) != 0;       // bit 2: ... as three planes h, m, l of Np x Kstride elements each (the fp32 contraction on split operands)
     it.transposed &= 1;
@@ -2231,22 +2286,7 @@ MCAV_EXPORT int mcav_pack_weights(const float* w_oihw, int Cout, int Cin, int kh
 namespace mcav {
 __global__ __launch_bounds__(256) void pack_upmerge_kernel(const float* w, int Cout, int Cin, int C1, int Np, float* out) {
     const size_t total = (size_t)4 * Np * 4 * C1;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int c = (int)(e % C1);
-        const int mt = (int)((e / C1) % 4), n = (int)((e / ((size_t)C1 * 4)) % Np), cls = (int)(e / ((size_t)C1 * 4 * Np));
-        const int py = cls >> 1, px = cls & 1, a = mt >> 1, b = mt & 1;
-        float sum = 0.f;
-        if (n < Cout) {
-            const float* wc = w + ((size_t)n * Cin + c) * 9;
-            for (int ky = 0; ky < 3; ++ky)
-                for (int kx = 0; kx < 3; ++kx) {
-                    const bool iny = py == 0 ? (a == 0 ? ky == 0 : ky >= 1) : (a == 0 ? ky <= 1 : ky == 2);
-                    const bool inx = px == 0 ? (b == 0 ? kx == 0 : kx >= 1) : (b == 0 ? kx <= 1 : kx == 2);
-                    if (iny && inx) sum += wc[ky * 3 + kx];
-                }
-        }
-        out[e] = sum;
-    }
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) out[e] = upmerge_elem(w, Cout, Cin, C1, Np, e);
 }
 }  // namespace mcav
 
@@ -2259,25 +2299,10 @@ MCAV_EXPORT int mcav_pack_weights_upmerge(const float* w_oihw, int Cout, int Cin
 }
 
 namespace mcav {
-// Adjoint counterpart: packed [n = c1][16 taps (u, v)][k = co], V[u][v][c1][co] = sum of w[co][c1][ky][kx] over ky in Sy(u), kx in Sy(v);
-// Sy(0) = {2}, Sy(1) = {1,2}, Sy(2) = {0,1}, Sy(3) = {0}.
+// Adjoint counterpart: packed [n = c1][16 taps (u, v)][k = co] (upmerge_adj_elem).
 __global__ __launch_bounds__(256) void pack_upmerge_adj_kernel(const float* w, int Cout, int Cin, int C1, int Np, int Kp, float* out) {
     const size_t total = (size_t)Np * 16 * Kp;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int k = (int)(e % Kp), tap = (int)((e / Kp) % 16), n = (int)(e / ((size_t)Kp * 16));
-        const int u = tap >> 2, v = tap & 3;
-        float sum = 0.f;
-        if (n < C1 && k < Cout) {
-            const float* wc = w + ((size_t)k * Cin + n) * 9;
-            for (int ky = 0; ky < 3; ++ky)
-                for (int kx = 0; kx < 3; ++kx) {
-                    const bool iny = u == 0 ? ky == 2 : (u == 1 ? ky >= 1 : (u == 2 ? ky <= 1 : ky == 0));
-                    const bool inx = v == 0 ? kx == 2 : (v == 1 ? kx >= 1 : (v == 2 ? kx <= 1 : kx == 0));
-                    if (iny && inx) sum += wc[ky * 3 + kx];
-                }
-        }
-        out[e] = sum;
-    }
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) out[e] = upmerge_adj_elem(w, Cout, Cin, C1, Kp, e);
 }
 }  // namespace mcav
 

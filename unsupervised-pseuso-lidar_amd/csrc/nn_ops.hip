@@ -76,6 +76,7 @@ __global__ void nhwc_to_nchw_kernel(const float* src, int B, int C, int H, int W
 // Stage 1 (only when there are many tiles): grid (C/64, slices, groups); a block sums one slice of the tiles for 64 channels
 // with 4 tile lanes, in fp64, into part[group][slice][2][C].  Stage 2: 32 channels x 8 slice lanes per block, fixed order.
 constexpr int BNF_SLICES = 128;        // upper bound of stage-1 slices
+constexpr int BNF_TICKETS = 256;       // completion tickets at the head of the finalize workspace: one per 64 channels (C <= 16384), 1 KB
 constexpr int BNF_DIRECT = 64;         // up to this many tiles the finalize kernel reads the fp32 slabs itself
 
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* stats, int mtiles, int C, int per_slice, double* part) {
@@ -521,9 +522,12 @@ MCAV_EXPORT int mcav_nhwc_to_nchw(const float* src, int B, int C, int H, int W, 
 MCAV_EXPORT size_t mcav_bn_finalize_workspace_bytes(int mtiles, int C, int groups) {
     if (groups < 1) groups = 1;
     if (mtiles <= BNF_DIRECT || C <= 0) return 0;
-    // the slices' partial sums + one completion ticket per 64-channel column (the caller zero-fills a workspace when it allocates it; the
-    // kernel leaves the tickets at zero)
-    return align_up(sizeof(double) * 2 * (size_t)C * BNF_SLICES * groups, 256) + align_up(sizeof(unsigned) * ((size_t)(C + 63) / 64), 256);
+    // one completion ticket per 64-channel column (the caller zero-fills a workspace when it allocates it; the kernel leaves the tickets at
+    // zero) + the slices' partial sums.  The tickets sit at a FIXED place and size, whatever C: a cached workspace serves layers of different
+    // widths, and a ticket word that another layer's partial sums had covered would not be zero (the first version put them behind the
+    // partials: every large-shape test failed).
+    if (C > 64 * BNF_TICKETS) return 0;
+    return sizeof(unsigned) * BNF_TICKETS + align_up(sizeof(double) * 2 * (size_t)C * BNF_SLICES * groups, 256);
 }
 
 MCAV_EXPORT int mcav_bn_finalize(const float* stats, int mtiles, int C, double count, const float* gamma, const float* beta, float eps, float momentum,
@@ -542,8 +546,8 @@ MCAV_EXPORT int mcav_bn_finalize(const float* stats, int mtiles, int C, double c
     int per_slice = (mtiles + BNF_SLICES - 1) / BNF_SLICES;
     if (per_slice < 8) per_slice = 8;
     const int slices = (mtiles + per_slice - 1) / per_slice;
-    double* part = reinterpret_cast<double*>(workspace);
-    unsigned* tickets = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + align_up(sizeof(double) * 2 * (size_t)C * BNF_SLICES * groups, 256));
+    unsigned* tickets = reinterpret_cast<unsigned*>(workspace);
+    double* part = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + sizeof(unsigned) * BNF_TICKETS);
     bn_partial_finalize_kernel<<<dim3((C + 63) / 64, slices, groups), 256, 0, s>>>(stats, mtiles, C, per_slice, part, tickets, count, gamma, beta, eps, momentum,
                                                                                    running_mean, running_var, scale, shift, save_mean, save_invstd);
     return launch_status();

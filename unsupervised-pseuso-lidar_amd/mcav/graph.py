@@ -62,6 +62,10 @@ class GraphedStep:
                 if self.capture_adam:
                     opt.step_capturable()
                 return out
+            # warm-up announces the buckets to a no-op: the batched slab reductions are then cut at the same points as under capture, so their
+            # device tables exist before it (building one is a host -> device copy, which a capturing stream refuses)
+            if self.sync is not None:
+                N.GRADS_READY = lambda params: None
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):

@@ -199,6 +199,17 @@ class PackRegistry:
         items = (_PackItem * len(live))()
         blk = 0
         for it, (spec, kind) in zip(items, live):
+            if kind in ("um", "ua"):                   # merged-tap copies of the decoder's upsample convolutions: C1 travels in `taps`
+                buf = spec._packs[kind]
+                it.src, it.dst = spec.weight.data_ptr(), buf.data_ptr()
+                it.Cout, it.Cin, it.taps = spec.cout, spec.cin, spec._merge_c1
+                if kind == "um":
+                    it.transposed, it.Np, it.Kp = 8, spec.np, 0
+                else:
+                    it.transposed, it.Np, it.Kp = 16, buf.shape[0], buf.shape[1] // 16
+                it.Kstride, it.first_block = 0, blk
+                blk += L.lib().mcav_pack_weights_blocks(it.taps, it.transposed, it.Np, max(it.Kp, 1))
+                continue
             tr, h = _KINDS[kind]
             buf = spec._packs[kind]
             np_, kp_ = (up16(spec.cin), up16(spec.cout)) if tr else (spec.np, spec.kp)
@@ -321,29 +332,36 @@ class ConvSpec:
 
     def packed_upmerge(self, c1):
         """Merged-tap copy for conv(cat(up2(x1), x2)) with reflection padding: [4 classes][Np][4 taps][c1] pre-summed filters of the
-        first c1 input channels (mcav_pack_weights_upmerge).  Small (one launch when stale); used on the forward stream only."""
-        key = self._key() + (c1,)
-        if getattr(self, "_upm", None) is None or self._key_u != key or self._upm.device != self.weight.device:
-            if getattr(self, "_upm", None) is None or self._upm.device != self.weight.device or self._upm.shape[-1] != c1:
-                self._upm = empty((4, self.np, 4, c1), self.weight)
-            L.check(L.lib().mcav_pack_weights_upmerge(P(self.weight), self.cout, self.cin, c1, P(self._upm), self.np, L.stream()),
-                    "mcav_pack_weights_upmerge")
-            self._key_u = key
-        return self._upm
+        first c1 input channels (mcav_pack_weights_upmerge).  First use: one small launch; afterwards a record of the registry's ONE re-packing
+        launch per optimiser step (round 4)."""
+        return self._merged("um", c1, lambda: empty((4, self.np, 4, c1), self.weight),
+                            lambda buf: L.lib().mcav_pack_weights_upmerge(P(self.weight), self.cout, self.cin, c1, P(buf), self.np, L.stream()))
+
+    def _merged(self, kind, c1, make, pack):
+        key = self._key()
+        buf = self._packs.get(kind)
+        if buf is None or buf.device != self.weight.device or getattr(self, "_merge_c1", c1) != c1:
+            if buf is not None and getattr(self, "_merge_c1", c1) != c1:
+                raise L.MCAVError("a convolution's merged-tap copies are built for ONE split of its input channels (got %d after %d)" % (c1, self._merge_c1))
+            self._merge_c1 = c1
+            first = buf is None
+            buf = self._packs[kind] = make()
+            L.check(pack(buf), "mcav_pack_weights_upmerge(%s)" % kind)
+            self._keys[kind] = key
+            if first:
+                PACKS.add(self, kind)
+        elif self._keys.get(kind) != key:
+            PACKS.repack_all(self.weight.device)       # one launch refreshes every registered copy (this one included)
+        return self._packs[kind]
 
     def packed_upmerge_adj(self, c1, bf16=False):
         """[up16(c1)][16 taps][up16(cout)]: the 4x4 stride-2 filter of the pooled upsample adjoint (mcav_pack_weights_upmerge_adj);
         bf16: its rounded copy for the bf16 MFMA kernel (mcav_f32_to_bf16)."""
+        npd, kpd = up16(c1), up16(self.cout)
+        upa = self._merged("ua", c1, lambda: empty((npd, 16 * kpd), self.weight),
+                           lambda buf: L.lib().mcav_pack_weights_upmerge_adj(P(self.weight), self.cout, self.cin, c1, P(buf), npd, kpd, L.stream()))
+        self._upa = upa
         key = self._key() + (c1,)
-        if getattr(self, "_upa", None) is None or self._key_ua != key or self._upa.device != self.weight.device:
-            npd, kpd = up16(c1), up16(self.cout)
-            if getattr(self, "_upa", None) is None or self._upa.device != self.weight.device or self._upa.shape[0] != npd:
-                self._upa = empty((npd, 16 * kpd), self.weight)
-                self._upa16 = None
-            L.check(L.lib().mcav_pack_weights_upmerge_adj(P(self.weight), self.cout, self.cin, c1, P(self._upa), npd, kpd, L.stream()),
-                    "mcav_pack_weights_upmerge_adj")
-            self._key_ua = key
-            self._key_ua16 = None
         if not bf16:
             return self._upa
         planes = 3 if bf16 == 3 else 1                      # bf16 = 3: the planes h, m, l (MMA_SPLIT)
@@ -752,6 +770,10 @@ class _WgradBatch:
         key = (str(self.device), bytes(arr))
         hit = self.tables.get(key)
         if hit is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise L.MCAVError("a batch of weight-gradient slab reductions was cut differently under hipGraph capture than in the warm-up step "
+                                  "(its device table does not exist yet, and building it is a host -> device copy): warm-up and capture must "
+                                  "announce the same gradient buckets (mcav/graph.py)")
             table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
             hit = self.tables[key] = (table, pb.value, rb.value, lds.value)
         table, npb, nrb, nlds = hit
