@@ -320,6 +320,9 @@ int mcav_adam_step_dev(float* param, const float* grad, float* exp_avg, float* e
 int mcav_event_create(void** event);
 int mcav_event_destroy(void* event);
 int mcav_event_record_external(void* event, void* stream);
+/* the wait side: on a capturing stream an external event-WAIT node (two captured graphs replayed on two streams order their work through
+ * record / wait pairs); otherwise hipStreamWaitEvent */
+int mcav_event_wait_external(void* event, void* stream);
 int mcav_stream_wait_event(void* stream, void* event);
 
 #ifdef __cplusplus

@@ -327,6 +327,36 @@ MCAV_EXPORT int mcav_event_record_external(void* event, void* stream) {
     return MCAV_OK;
 }
 
+// The wait side of the same mechanism.  On a CAPTURING stream: an external event-WAIT node (the graph's later nodes wait, on every replay, for
+// the event as another graph or stream last recorded it: two captured graphs replayed on two streams order their work through such pairs,
+// mcav/graph.py's weight-gradient graph).  On a stream that is not capturing: hipStreamWaitEvent.
+MCAV_EXPORT int mcav_event_wait_external(void* event, void* stream) {
+    if (!event) return MCAV_E_INVALID;
+    hipStream_t s = as_stream(stream);
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    hipError_t e = hipStreamIsCapturing(s, &st);
+    if (e != hipSuccess) { (void)hipGetLastError(); return -(2000 + (int)e); }
+    if (st != hipStreamCaptureStatusActive) {
+        e = hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(event), 0);
+        if (e != hipSuccess) { (void)hipGetLastError(); return -(1000 + (int)e); }
+        return MCAV_OK;
+    }
+    unsigned long long id = 0;
+    hipGraph_t graph = nullptr;
+    const hipGraphNode_t* deps = nullptr;
+    size_t ndeps = 0;
+    e = hipStreamGetCaptureInfo_v2(s, &st, &id, &graph, &deps, &ndeps);
+    if (e == hipSuccess && graph) {
+        hipGraphNode_t node = nullptr;
+        e = hipGraphAddEventWaitNode(&node, graph, deps, ndeps, reinterpret_cast<hipEvent_t>(event));
+        if (e == hipSuccess) e = hipStreamUpdateCaptureDependencies(s, &node, 1, hipStreamSetCaptureDependencies);
+        if (e == hipSuccess) return MCAV_OK;
+    }
+    fprintf(stderr, "mcav_event_wait_external: explicit event-wait node: %s\n", hipGetErrorName(e));
+    (void)hipGetLastError();
+    return -(1000 + (int)e);
+}
+
 MCAV_EXPORT int mcav_stream_wait_event(void* stream, void* event) {
     if (!event) return MCAV_E_INVALID;
     if (hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(event), 0) != hipSuccess) { (void)hipGetLastError(); return MCAV_E_LAUNCH; }

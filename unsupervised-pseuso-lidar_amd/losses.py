@@ -49,11 +49,14 @@ class _WarpLossFn(torch.autograd.Function):
         args, tail, flags, keep = ctx.rerun
         g_dt, g_dr, g_p = ctx.grads
         dev = g_dt.device
-        up = torch.zeros(2, dtype=torch.float32, device=dev)
-        if g0 is not None:
-            up[0:1].copy_(g0.reshape(1))
-        if g1 is not None:
-            up[1:2].copy_(g1.reshape(1))
+        if g0 is not None and g1 is not None:          # the usual case (sum(loss).backward()): ONE launch instead of a fill and two copies
+            up = torch.stack([g0.reshape(()), g1.reshape(())]).to(dtype=torch.float32, device=dev)
+        else:
+            up = torch.zeros(2, dtype=torch.float32, device=dev)
+            if g0 is not None:
+                up[0:1].copy_(g0.reshape(1))
+            if g1 is not None:
+                up[1:2].copy_(g1.reshape(1))
         scratch = torch.empty(2, dtype=torch.float32, device=dev)
         tail = list(tail)
         tail[1] = L.ptr(scratch)        # loss values are not needed again

@@ -93,6 +93,7 @@ L.register({
     "mcav_event_create": (c_i, [ctypes.POINTER(c_p)]),
     "mcav_event_destroy": (c_i, [c_p]),
     "mcav_event_record_external": (c_i, [c_p, c_p]),
+    "mcav_event_wait_external": (c_i, [c_p, c_p]),
     "mcav_stream_wait_event": (c_i, [c_p, c_p]),
     "mcav_kernel_timer_begin": (c_i, []),
     "mcav_kernel_timer_count": (c_i, []),
@@ -658,6 +659,10 @@ class _WgradSide:
         self.mains = []            # streams a network backward ran on during this backward pass
         self.in_backward = False
         self.forked = False
+        self.dual = None           # set by mcav/graph.py while TWO graphs are captured at once (main chain / weight-gradient chain): an object
+                                   # with .stream (the side stream, capturing its own graph), .fork(main) and .join(main) -- external
+                                   # event record / wait node pairs instead of the eager path's cross-stream event waits, which would
+                                   # merge the side stream into the main stream's capture
 
     def _note(self, main):
         if not self.in_backward:
@@ -675,6 +680,16 @@ class _WgradSide:
             return fn()
         from . import streams
         main = torch.cuda.current_stream()
+        if self.dual is not None and main == self.dual.stream:
+            return fn()                          # already on the side chain (the pose network's backward under a two-graph capture): in order as it is
+        if self.dual is not None and self.enabled and self._note(main):
+            self.stream = self.dual.stream
+            self.dual.fork(main)                 # side graph: wait for what the main graph has recorded up to here
+            with torch.cuda.stream(self.stream):
+                fn()
+            self.keep.append(tensors)
+            self.forked = True
+            return
         if not self._note(main) or not self.enabled or PROFILE is not None or streams.SERIAL:
             return fn()
         if self.stream is None or self.stream.device != main.device:
@@ -688,7 +703,9 @@ class _WgradSide:
     def join(self):
         cur = torch.cuda.current_stream()
         flush_wgrad_batch()                  # the last gradient bucket's slabs: reduced behind their GEMMs, on the stream those ran on
-        if self.forked:
+        if self.forked and self.dual is not None:
+            self.dual.join(cur)                  # main graph: wait for the side graph's last node (one stream under capture: mains == [cur])
+        elif self.forked:
             for m in self.mains:
                 m.wait_stream(self.stream)
             cur.wait_stream(self.stream)

@@ -22,6 +22,13 @@ def _tensors(obj):
 # capture everything is issued on the capturing stream -- same launches, no cross-stream edges in the graph.
 SERIAL = False
 
+# Set by mcav/graph.py while a step is captured as main-chain and side-chain graphs (class _DualCapture): the side stream captures graphs of
+# its own.  A Branch then runs the pose network's launches on that side stream (models/pose/pose_net.py switches streams INSIDE its autograd
+# node, so that autograd sees one stream and adds no cross-stream event of its own, which would tie the two captures together), and
+# Branch.join() is where the pair of graphs is cut: what follows on the main stream needs the branch's result, and a graph can only wait for
+# another graph's node through the host (see _DualCapture.join).
+DUAL = None
+
 
 class Branch:
     def __init__(self):
@@ -30,7 +37,8 @@ class Branch:
 
     def fork(self, fn, *args):
         """Run fn(*args) on the branch stream, ordered after everything already queued on the current stream."""
-        self.inline = SERIAL or not any(t.is_cuda for t in _tensors(args))
+        self.inline = SERIAL or DUAL is not None or not any(t.is_cuda for t in _tensors(args))
+        self.cut = DUAL is not None
         if self.inline:
             return fn(*args)
         cur = torch.cuda.current_stream()
@@ -46,6 +54,8 @@ class Branch:
     def join(self, out):
         """Make the current stream wait for the branch; `out` (tensors made on the branch) becomes safe to use on it."""
         if self.inline:
+            if getattr(self, "cut", False) and DUAL is not None:
+                DUAL.split()                       # two-graph capture: the main chain continues in the next graph, behind the side chain's
             return out
         cur = torch.cuda.current_stream()
         cur.wait_stream(self.stream)

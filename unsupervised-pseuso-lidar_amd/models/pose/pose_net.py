@@ -17,16 +17,39 @@ def conv_gn(in_planes, out_planes, kernel_size=3):
 
 
 class _PoseNetFn(torch.autograd.Function):
+    """Under a two-graph capture (mcav/graph.py, streams.DUAL) both directions run on the side stream, switched to INSIDE the node: autograd
+    then sees the node on the main stream and adds no cross-stream event of its own."""
+
     @staticmethod
     def forward(ctx, mod, tgt, ref0, ref1, *params):
+        from mcav import streams
         imgs = [L.dev(t.contiguous(), "image") for t in (tgt, ref0, ref1)]
-        out, saved = E.forward(mod, imgs[0], imgs[1:])
+        dual = streams.DUAL
+        if dual is not None:
+            dual.fork(torch.cuda.current_stream())            # side chain: behind the inputs and the re-packed filters
+            with torch.cuda.stream(dual.stream):
+                out, saved = E.forward(mod, imgs[0], imgs[1:])
+        else:
+            out, saved = E.forward(mod, imgs[0], imgs[1:])
         ctx.mod, ctx.saved = mod, saved
         return out.view(out.shape[0], mod.nb_ref_imgs, 6)
 
     @staticmethod
     def backward(ctx, g):
+        from mcav import nn as N
+        from mcav import streams
         g = L.dev(g.contiguous(), "grad")
+        dual = streams.DUAL
+        if dual is not None and N.WGRAD_SIDE.dual is dual:
+            main = torch.cuda.current_stream()
+            if N.WGRAD_SIDE._note(main):                      # (the end-of-backward callback records the side chain's join event)
+                N.WGRAD_SIDE.stream, N.WGRAD_SIDE.forked = dual.stream, True
+                N.WGRAD_SIDE.keep.append((g,))
+                dual.fork(main)                                # side chain: behind the loss kernel's pose gradient
+                with torch.cuda.stream(dual.stream):
+                    E.backward(ctx.mod, ctx.saved, g.view(g.shape[0], -1))
+                ctx.saved = None
+                return (None,) * (4 + len(list(ctx.mod.parameters())))
         E.backward(ctx.mod, ctx.saved, g.view(g.shape[0], -1))
         ctx.saved = None
         return (None,) * (4 + len(list(ctx.mod.parameters())))
