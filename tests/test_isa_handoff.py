@@ -15,17 +15,16 @@ import subprocess
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(REPO, "unsupervised-pseuso-lidar_amd", "csrc", "warp_loss.hip")
+CSRC = os.path.join(REPO, "unsupervised-pseuso-lidar_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-@pytest.fixture(scope="module")
-def kernels(tmp_path_factory):
+def _device_functions(tmp_path_factory, source):
     if not os.path.exists(HIPCC) and shutil.which("hipcc") is None:
         pytest.skip("hipcc not available")
-    out = str(tmp_path_factory.mktemp("isa") / "warp_loss.s")
+    out = str(tmp_path_factory.mktemp("isa") / (source + ".s"))
     subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
-                           "-o", out, SRC], stderr=subprocess.DEVNULL)
+                           "-o", out, os.path.join(CSRC, source)], stderr=subprocess.DEVNULL)
     text = open(out).read()
     # split into functions: "<name>:" at column 0 up to its ".Lfunc_end"
     funcs = {}
@@ -33,6 +32,16 @@ def kernels(tmp_path_factory):
         body = [l.strip() for l in m.group(2).splitlines()]
         funcs[m.group(1)] = [l for l in body if l and not l.startswith((";", ".", "//")) or l.startswith(".LBB")]
     return funcs
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    return _device_functions(tmp_path_factory, "warp_loss.hip")
+
+
+@pytest.fixture(scope="module")
+def nn_kernels(tmp_path_factory):
+    return _device_functions(tmp_path_factory, "nn_ops.hip")
 
 
 def _ticket_kernels(funcs):
@@ -76,3 +85,17 @@ def test_published_words_and_finisher_reads_are_agent_scope(kernels):
         sc1_after = [i for i in after if i.startswith("global_store") and " sc1" in i]
         assert len(sc1_after) >= 3, "%s: sample sums / ticket resets are not agent-scope stores: %s" % (name, sc1_after)
         assert not any(i.startswith(("buffer_wbl2", "buffer_inv")) for i in body), "%s: an L2 write-back / invalidate crept in" % name
+
+
+def test_batchnorm_finalize_hand_off(nn_kernels):
+    """bn_partial_finalize_kernel (csrc/nn_ops.hip: stage-1 partial sums and the finalize in one launch, round 4) uses the same protocol: its
+    partial sums are stored sc1, every thread waits vmcnt(0) before the column's ticket, the finisher loads sc1 and resets the ticket sc1."""
+    tk = {n: b for n, b in _ticket_kernels(nn_kernels).items() if "bn_partial_finalize" in n}
+    assert tk, list(nn_kernels)[:5]
+    test_stores_are_acknowledged_before_every_ticket(tk)
+    for name, body in tk.items():
+        first = next(i for i, ins in enumerate(body) if ins.startswith("global_atomic_add"))
+        assert any(i.startswith("global_store") and " sc1" in i for i in body[:first]), name
+        assert sum(1 for i in body[first:] if i.startswith("global_load") and " sc1" in i) >= 2, name
+        assert any(i.startswith("global_store") and " sc1" in i for i in body[first:]), name
+        assert not any(i.startswith(("buffer_wbl2", "buffer_inv")) for i in body), name

@@ -33,7 +33,7 @@ class _DualCapture:
     side graph's last node records an event, both captures end, the next pair begins in the same memory pools) and the host orders the main
     stream behind that event between the launches (GraphedStep.__call__): main[0], side[0], wait, main[1], side[1], wait, Adam."""
 
-    def __init__(self, device, nevents=192):
+    def __init__(self, device, nevents=1024):
         from . import lib as L
         self.L = L
         self.stream = torch.cuda.Stream(device=device)            # side chain
@@ -47,9 +47,16 @@ class _DualCapture:
         self.main_graphs, self.side_graphs, self.cut_events = [], [], []
         self.join_event = None
 
+    def __del__(self):
+        try:
+            for ev in self.events:
+                self.L.lib().mcav_event_destroy(ev)
+        except Exception:
+            pass
+
     def _next(self):
-        if self.used >= len(self.events):
-            raise self.L.MCAVError("two-graph capture: more fork points than events")
+        if self.used >= len(self.events):      # (one event per weight-gradient launch of the step: ~50 for ResNet-18, ~120 for ResNet-50)
+            raise self.L.MCAVError("two-graph capture: more than %d fork points in one step" % len(self.events))
         ev = self.events[self.used]
         self.used += 1
         return ev
@@ -93,9 +100,11 @@ class _DualCapture:
         L.check(L.lib().mcav_event_record_external(ev, L.c_p(self.stream.cuda_stream)), "mcav_event_record_external(join)")
         self.join_event = ev
 
-    def end(self):
+    def end(self, failed=False):
         self._end_pair()
-        if self.join_event is None:                # a step without a backward pass: the last pair ends like a cut
+        if failed:                                 # the step raised: the captures are closed, the caller re-raises
+            return
+        if self.join_event is None:                # a step without a backward pass has no join to order Adam behind
             raise self.L.MCAVError("two-graph capture: the step never joined its side chain (no backward pass?)")
         self.cut_events.append(self.join_event)
 
@@ -149,9 +158,9 @@ class GraphedStep:
             else:
                 L.check(L.lib().mcav_event_record_external(ev, L.stream()), "mcav_event_record_external")
             self.marks.append((r, ev))
-        # This ROCm replays the captured branches on one queue (rounds 1-2), so the step is captured on ONE stream: same launches, no
-        # cross-stream edges.  (Round 3 tried to keep the three streams in the capture and force the runtime's parallel graph queues,
-        # DEBUG_HIP_FORCE_GRAPH_QUEUES=4: the process died inside the capture without a Python error; not pursued.)
+        # This ROCm replays the captured branches of ONE graph on one queue (rounds 1-2), so nothing is gained by cross-stream edges inside a
+        # capture: the eager path's side streams are switched off (SERIAL) and the step is captured either on one stream (dual=False) or as
+        # two chains of graphs on two streams that the host and external event nodes keep in order (_DualCapture, the default).
         serial0, streams.SERIAL = streams.SERIAL, True
         try:
             want_dual = DUAL_DEFAULT if dual is None else bool(dual)
@@ -199,6 +208,14 @@ class GraphedStep:
         opt._dev_mirror = None
         arena.bump()
 
+    def __del__(self):
+        try:
+            from . import lib as L
+            for ev in getattr(self, "_events", ()):
+                L.lib().mcav_event_destroy(ev)
+        except Exception:
+            pass
+
     def _capture_dual(self, whole, device):
         """Main chain and side chain as pairs of graphs captured at the same time (class _DualCapture)."""
         from . import nn as N
@@ -212,8 +229,10 @@ class GraphedStep:
             try:
                 with torch.cuda.stream(self.dual.main_stream):
                     out = whole()
-            finally:
-                self.dual.end()
+            except BaseException:
+                self.dual.end(failed=True)
+                raise
+            self.dual.end()
         finally:
             N.WGRAD_SIDE.dual = None
             N.WGRAD_SIDE.stream = None
