@@ -66,9 +66,10 @@ def test_losses_ka1(golden):
     sum(out).backward()
     norms = [float(dt.grad.norm()), float(dr.grad.norm()), float(p.grad.norm())]
     assert np.allclose(norms, g["grad_norms"], rtol=2e-3)
-    # KA1 uses white-noise images and near-identity poses: many samples sit within rounding of an integer source
-    # coordinate, where the bilinear derivative jumps; the pose gradient is a random-walk sum over pixels, so a couple
-    # of such pixels move it at the 1e-3..1e-2 level (measured 4e-3 on MI355X vs the CPU reference).
+    # KA1 uses white-noise images and near-identity poses: many samples sit within rounding of an integer source coordinate, where the
+    # bilinear derivative jumps, and a couple of such pixels move the pose gradient at the 1e-3 .. 1e-2 level.  The 4e-3 measured here is the
+    # GOLDEN's distance (the reference's fp32 run on the CPU decides a few of those pixels the other way than float64), not the kernel's:
+    # against float64 on the identical inputs the HIP kernel decides every pixel alike and sits 4.9e-6 away (asserted at the end of the test).
     assert rel_err(p.grad, g["g_poses"]) < 2e-2
     # ... and the arbiter under that bound: the same inputs through the oracle in float64 and in float32.  The HIP gradients must be as
     # close to the float64 ones as stock PyTorch fp32 is (a real indexing error would not be).
@@ -88,7 +89,7 @@ def test_losses_ka1(golden):
     flips, gap, after, bad = ff.report("KA1 L1 kernel", taps, dposes, o64)
     print("KA1: %d pixels decided differently from float64, pose-gradient gap %.2e before, %.2e with float64 taking their side" % (len(flips), gap, after))
     assert not bad, "pixels decided differently from float64 WITHOUT a tie to explain it: %s" % bad
-    assert after < 1e-4, (gap, after)
+    assert after < 2e-5, (gap, after)          # (measured on MI355X, round 4: no pixel differs, 4.9e-6)
 
 
 def oracle_loss_grads(tgt, refs, disp_t, disp_r, poses, K, ssim_weight=0.0, envelope=2):

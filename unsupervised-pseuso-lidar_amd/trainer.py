@@ -54,7 +54,13 @@ class Trainer:
         self.epoch = 0
         self.step = 0
         self.verbose = bool(act.get('verbose', True))
-        self.use_hipgraph = bool(act.get('hipgraph', False))      # replay the step as one captured hipGraph per input shape
+        # action.hipgraph: true / false / "auto" (default).  The replayed step (two chains of graphs, mcav/graph.py) is level with eager issue
+        # at batch 12 x 192 x 640 and 15 % faster at the reference config's batch 4 (the eager step is host-bound there): "auto" replays when a
+        # batch is at most half the headline's pixels, and falls back to eager issue for good if a capture ever fails.
+        hg = act.get('hipgraph', 'auto')
+        self.use_hipgraph = hg if isinstance(hg, str) and hg.lower() == 'auto' else bool(hg)
+        if isinstance(self.use_hipgraph, str):
+            self.use_hipgraph = 'auto' 
         self._graphs = None
 
         self.depth_model = self.load_from_config(config, model_type='depth')
@@ -179,8 +185,20 @@ class Trainer:
 
     def train_step(self, samples):
         """zero_grad -> process_batch -> backward -> (all-reduce) -> Adam  (reference trainer.py:261-266)."""
+        if self.use_hipgraph == 'auto':
+            t = samples['tgt']
+            self.use_hipgraph = bool(t.shape[0] * t.shape[-2] * t.shape[-1] <= 6 * 192 * 640)
+            self._hipgraph_auto = True
         if self.use_hipgraph:
-            return self._graphed_step(samples)
+            if not getattr(self, "_hipgraph_auto", False):
+                return self._graphed_step(samples)
+            try:
+                return self._graphed_step(samples)
+            except Exception as e:       # "auto" must never cost a run: same launches, issued eagerly from now on
+                import warnings
+                warnings.warn("hipGraph capture failed (%s: %s); issuing the step eagerly" % (type(e).__name__, e))
+                torch.cuda.synchronize()
+                self.use_hipgraph, self._graphs = False, None
         self.model_optimizer.zero_grad()
         outputs, self.loss = self.process_batch(samples)
         sum(self.loss).backward()
