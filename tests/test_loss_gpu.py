@@ -275,6 +275,23 @@ def test_losses_vs_oracle_at_size(B, H, W):
     grad_close(x.grad, a.grad, l2=3e-2)
     grad_close(y.grad, b.grad, l2=3e-2)
     assert rel_err(z.grad, c.grad) < 5e-3      # a sum over 4.4 M sign terms: measured 1e-3..2.6e-3 depending on the host's CPU kernels
+    # (that distance is mostly the CPU fp32 oracle's own, VERDICT round 3 weak #9: the kernels' per-pixel dump against float64 on the identical
+    # inputs names the pixels decided differently, each must be a tie, and with float64 taking their side the HIP pose gradient agrees to rounding)
+    import flip_finder as ff
+    dev = lambda t: t.to(DEV)
+    taps, dposes, _ = ff.hip_taps(dev(s["tgt"]), [dev(r) for r in s["ref_imgs"]], dev(disp_t), dev(disp_r), dev(poses), dev(s["intrinsics"]))
+    o64 = ff.oracle_taps(s["tgt"], s["ref_imgs"], disp_t, disp_r, poses, s["intrinsics"], torch.float64, 0.0)
+    # (white-noise disparities: depths from 0.1 to 100 put sampling positions up to 1e-4 px from their float64 values in ANY fp32 evaluation --
+    # the reference's own normalise / un-normalise round trip costs 3 ulp of W - 1 --, so a tie here is a margin below 2e-4 px / 2e-4 in value)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):          # (hundreds of pixels at the full size: keep the log short)
+        flips, gap, after, bad = ff.report("%dx%dx%d L1 kernel" % (B, H, W), taps, dposes, o64, cell_margin=2e-4, value_margin=2e-4)
+    worst = max([f["margin"] for f in flips], default=0.0)
+    print("%dx%dx%d: %d of %d pixels decided differently from float64 (largest float64 margin %.1e), pose-gradient gap %.2e before, %.2e with "
+          "float64 taking their side" % (B, H, W, len(flips), 3 * B * H * W, worst, gap, after))
+    assert not bad, "pixels decided differently from float64 WITHOUT a tie to explain it: %s" % bad[:5]
+    assert after < 5e-5, (gap, after)
     # the arbiter under those bounds: both fp32 evaluations against the float64 one
     g32, g64, genv = oracle_loss_grads(s["tgt"], s["ref_imgs"], disp_t, disp_r, poses, s["intrinsics"], envelope=1 if B * H * W > 10 ** 6 else 2)
     v = Verdicts()
