@@ -391,6 +391,11 @@ __device__ __forceinline__ int patch_pixel(int R) {
     return (R & ~31) + (g0 ? 0 : 16) + idx;
 }
 
+// n / d for the small non-negative integers of the patch kernels' set-up (n < 2^20, d < 2^10), exact: (n + 0.5) / d is at least 0.5 / d away
+// from an integer, far more than the rounding of the float product.  An integer division by a run-time value is ~40 vector instructions on
+// this ISA, and a patch-kernel workgroup of the 48x160 maps lives for only 6 stages.
+__device__ __forceinline__ int small_div(int n, float rcp_d) { return (int)(((float)n + 0.5f) * rcp_d); }
+
 struct PatchGeo {
     int TH, TW, tiles_y, tiles_x;
     int tmb;      // 32-row blocks per wavefront: 1 = 64-pixel blocks, 2 = 128-pixel blocks
@@ -439,12 +444,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
     const GatherSrc& g = p.g;
     const int TH = geo.TH, TW = geo.TW, PW = TW + 2, PH = TH + 2;
     const int per_img = geo.tiles_y * geo.tiles_x;
-    const int img = mt / per_img, tr = mt - img * per_img;
-    const int ty0 = (tr / geo.tiles_x) * TH, tx0 = (tr % geo.tiles_x) * TW;
+    const float rcp_pw = 1.0f / (float)PW, rcp_tw = 1.0f / (float)TW;
+    const int img = small_div(mt, 1.0f / (float)per_img), tr = mt - img * per_img;
+    const int tyi = small_div(tr, 1.0f / (float)geo.tiles_x);
+    const int ty0 = tyi * TH, tx0 = (tr - tyi * geo.tiles_x) * TW;
 
     if (tid < BM) {
         const int pix = patch_pixel(tid);
-        const int py = pix / TW, px = pix - py * TW;
+        const int py = small_div(pix, rcp_tw), px = pix - py * TW;
         const int y = ty0 + py, x = tx0 + px;
         s_out[tid] = (py < TH && y < p.Hd && x < p.Wd) ? (unsigned)((img * p.Hd + y) * p.Wd + x) * (unsigned)(p.Cd * 4) : OOB;
     }
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
 #pragma unroll
     for (int j = 0; j < C::NJ; ++j) {
         const int pp = pp0 + 32 * j;
-        const int ppy = pp / PW, ppx = pp - ppy * PW;
+        const int ppy = small_div(pp, rcp_pw), ppx = pp - ppy * PW;
         const int y = ty0 - 1 + ppy, x = tx0 - 1 + ppx;
         const bool ok = pp < PH * PW && (unsigned)y < (unsigned)g.Hs && (unsigned)x < (unsigned)g.Ws;
         aoff[j] = ok ? (unsigned)((((img * g.Hs + y) * g.Ws + x) * g.C1 + c4 * 4) * 4) : OOB;
@@ -520,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
 #pragma unroll
     for (int i = 0; i < TMB; ++i) {
         const int pix = patch_pixel(wm0 + 32 * i + frow);
-        const int py = pix / TW, px = pix - py * TW;
+        const int py = small_div(pix, rcp_tw), px = pix - py * TW;
         prow[i] = py < TH ? py * PW + px : 0;                    // rows past the block multiply pixel 0 (their results are dropped)
     }
     const int fslot = lane >> 5;                                  // which 16-byte half of a k-step this lane holds
