@@ -399,6 +399,8 @@ __device__ __forceinline__ int small_div(int n, float rcp_d) { return (int)(((fl
 struct PatchGeo {
     int TH, TW, tiles_y, tiles_x;
     int tmb;      // 32-row blocks per wavefront: 1 = 64-pixel blocks, 2 = 128-pixel blocks
+    int refl;     // 0 zero padding; 1 reflection padding, forward (the patch's ring is the mirrored row / column); 2 the ADJOINT of reflection
+                  // padding (the zero-padded data gradient plus the ring's contributions folded onto rows / columns 1 and H - 2 / W - 2)
 };
 
 // Timing experiments only, WRONG results: a compile-time value of experiment builds (make variant NAME=pd8 FLAGS=-DMCAV_PATCH_DIAG=8), zero
@@ -416,7 +418,7 @@ struct PatchCfg {                       // TMB 32-row blocks per wavefront: 64- 
     using T = typename std::conditional<TMB == 1, BT64x64k32, BT128x64k32>::type;
 };
 
-template <int NS, int TMB>
+template <int NS, int TMB, bool ADJ = false>                      // ADJ: the adjoint of reflection padding (geo.refl == 2), a form of its own
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, const u16* __restrict__ w16, PatchGeo geo) {
     using C = PatchCfg<TMB>;
     using T = typename C::T;
@@ -462,7 +464,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
     for (int j = 0; j < C::NJ; ++j) {
         const int pp = pp0 + 32 * j;
         const int ppy = small_div(pp, rcp_pw), ppx = pp - ppy * PW;
-        const int y = ty0 - 1 + ppy, x = tx0 - 1 + ppx;
+        int y = ty0 - 1 + ppy, x = tx0 - 1 + ppx;
+        if (geo.refl == 1) {                                      // reflection padding: the ring of the MAP is its row / column 1, H - 2 / W - 2
+            y = y < 0 ? -y : (y >= g.Hs ? 2 * g.Hs - 2 - y : y);  // (rows further out belong to dropped outputs of a ragged block: zero if past the map)
+            x = x < 0 ? -x : (x >= g.Ws ? 2 * g.Ws - 2 - x : x);
+        }
         const bool ok = pp < PH * PW && (unsigned)y < (unsigned)g.Hs && (unsigned)x < (unsigned)g.Ws;
         aoff[j] = ok ? (unsigned)((((img * g.Hs + y) * g.Ws + x) * g.C1 + c4 * 4) * 4) : OOB;
     }
@@ -524,17 +530,79 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
     const int frow = lane & 31;
     // this lane's A rows = output pixels (py, px) of the block -> patch pixel (py + dy, px + dx), dy / dx = the tap (mirrored for the data gradient)
     int prow[TMB];
+    unsigned rmask[TMB];                                         // reflection adjoint: bit 0 / 1 this row's pixel is in map row 1 / H - 2, bit 2 / 3 in column 1 / W - 2
 #pragma unroll
     for (int i = 0; i < TMB; ++i) {
         const int pix = patch_pixel(wm0 + 32 * i + frow);
         const int py = small_div(pix, rcp_tw), px = pix - py * TW;
         prow[i] = py < TH ? py * PW + px : 0;                    // rows past the block multiply pixel 0 (their results are dropped)
+        const int y = ty0 + py, x = tx0 + px;
+        rmask[i] = (ADJ && py < TH) ? (unsigned)(y == 1) | ((unsigned)(y == p.Hd - 2) << 1) | ((unsigned)(x == 1) << 2) | ((unsigned)(x == p.Wd - 2) << 3) : 0u;
     }
     const int fslot = lane >> 5;                                  // which 16-byte half of a k-step this lane holds
     const int brow = wn0 + frow;
     const u16* const b_lane0 = Bs + brow * LDH + ((fslot ^ ((brow >> 2) & 3)) * 8);            // k-step 0 / 1 of this lane's filter row
     const u16* const b_lane1 = Bs + brow * LDH + (((2 + fslot) ^ ((brow >> 2) & 3)) * 8);
     const bool fwd = g.sign > 0;
+    // The adjoint of reflection padding (geo.refl == 2; the decoder's 3x3 convolutions, reference layers.py Conv3x3 / ReflectionPad2d(1)).
+    // Forward, y[q] = sum_k W_k x[refl(q + k - 1)]: the ring pixel -1 IS pixel 1, H is H - 2.  So dx[p] = sum_k W_k^T (sum over the q with
+    // refl(q + k - 1) = p of dy[q]): the zero-padded data gradient (q = p + 1 - k where that is inside the map) plus, for p in row 1, the
+    // q = -k of filter row k = 0 (q = 0: "source one row UP" = the fragment the mirrored filter row 2 reads), for p in row H - 2 filter row 2
+    // with the source one row down, the same per column, and the four products of both for the pixels (1 | H - 2, 1 | W - 2).  Each extra
+    // term is an MFMA group of a filter tap with the patch view of the OPPOSITE tap, its A rows zeroed except in the lanes of that row /
+    // column: only the blocks that touch rows 1 / H - 2 or columns 1 / W - 2 run them (block-uniform branches), after the stage's own steps.
+    const bool has_y1 = ADJ && ty0 <= 1 && ty0 + TH > 1, has_yl = ADJ && ty0 <= p.Hd - 2 && ty0 + TH > p.Hd - 2;
+    const bool has_x1 = ADJ && tx0 <= 1 && tx0 + TW > 1, has_xl = ADJ && tx0 <= p.Wd - 2 && tx0 + TW > p.Wd - 2;
+    auto extras = [&](int ky) {
+        auto afr = [&](int t, int sky, int skx, int ks, bf16x8 (&a)[NS], bool keep) {          // the view tap (sky, skx) of the data gradient reads
+            const int row = prow[t] + (2 - sky) * PW + 2 - skx;
+            const u16* const ap = Ap + row * LDH + (((2 * ks + fslot) ^ ((row >> 2) & 3)) * 8);
+            const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(ap + q * APL);
+                a[q] = keep ? v : zero;
+            }
+        };
+        auto mma = [&](int t, const bf16x8 (&a)[NS], const bf16x8 (&b)[NS]) {
+            if constexpr (NS == 1) {
+                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[t][0], 0, 0, 0);
+            } else {
+                low[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], low[t], 0, 0, 0);
+                mid[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], mid[t], 0, 0, 0);
+                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[t][0], 0, 0, 0);
+                low[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], low[t], 0, 0, 0);
+                mid[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], mid[t], 0, 0, 0);
+                low[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], low[t], 0, 0, 0);
+            }
+        };
+        const bool yrow = (ky == 0 && has_y1) || (ky == 2 && has_yl);
+        const unsigned ybit = ky == 0 ? 1u : 2u;
+        const int sky = 2 - ky;                                                               // the opposite filter row's view
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 b[3][NS];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const u16* const bp = (ks ? b_lane1 : b_lane0) + kx * NS * BPL;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) b[kx][q] = *reinterpret_cast<const bf16x8*>(bp + q * BPL);
+            }
+#pragma unroll
+            for (int t = 0; t < TMB; ++t) {
+                const unsigned m = rmask[t];
+                bf16x8 a[NS];
+                if (has_x1) { afr(t, ky, 2, ks, a, (m & 4u) != 0); mma(t, a, b[0]); }
+                if (has_xl) { afr(t, ky, 0, ks, a, (m & 8u) != 0); mma(t, a, b[2]); }
+                if (yrow) {
+                    const bool my = (m & ybit) != 0;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) { afr(t, sky, kx, ks, a, my); mma(t, a, b[kx]); }
+                    if (has_x1) { afr(t, sky, 2, ks, a, my && (m & 4u)); mma(t, a, b[0]); }
+                    if (has_xl) { afr(t, sky, 0, ks, a, my && (m & 8u)); mma(t, a, b[2]); }
+                }
+            }
+        }
+    };
     // A stage's six steps (three taps x two 16-deep k-steps), software-pipelined by hand: the fragments of step i + 1 are read from LDS while
     // the MFMAs of step i run (left to itself the compiler waits for each ds_read right in front of the MFMA that uses it).
     auto compute = [&](int ky) {
@@ -598,6 +666,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
         const bool more = chunk + 1 < nchunks;
         if (ky == 0 && more && !(diag & 4)) issueA(ra, chunk + 1);               // lands during the chunk's three stages
         if (!(diag & 8)) compute(ky);
+        if constexpr (ADJ) {
+            if (has_y1 | has_yl | has_x1 | has_xl) extras(ky);
+        }
         if (!(diag & 2)) __syncthreads();
         if (ky == 2 && more && !(diag & 4)) storeA(ra);
         if (s + 1 < total) {
@@ -1086,8 +1157,20 @@ static bool patch_plan(const mcav_igemm_desc* d, PatchGeo& geo, bool f32 = false
     static const int enabled = MCAV_KNOB_INT("MCAV_PATCH", 1);
     if (!enabled || !d) return false;
     if (f32 ? (d->mma != 0 || !d->w) : (!d->w16 || d->mma < 1 || d->mma > 3)) return false;
-    if (d->mode != MCAV_G_DIRECT || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_mode != MCAV_PAD_ZERO) return false;
-    if (!((d->sign == 1 && d->offset == -1) || (d->sign == -1 && d->offset == 1))) return false;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1) return false;
+    geo.refl = 0;
+    if (d->mode == MCAV_G_DIRECT && d->pad_mode == MCAV_PAD_REFLECT && d->sign == 1 && d->offset == -1) geo.refl = 1;
+    else if (d->mode == MCAV_G_ADJ_REFLECT && d->sign == -1 && d->offset == 1) geo.refl = 2;
+    else if (d->mode != MCAV_G_DIRECT || d->pad_mode != MCAV_PAD_ZERO) return false;
+    else if (!((d->sign == 1 && d->offset == -1) || (d->sign == -1 && d->offset == 1))) return false;
+    // reflection padding and its adjoint (the decoder's single-source 3x3 layers; round 4): the split form only
+    static const int refl_on = MCAV_KNOB_INT("MCAV_PATCH_REFLECT", 1);
+    if (geo.refl && (f32 || d->mma < 2 || !refl_on || d->Hs < 2 || d->Ws < 2)) return false;
+    // ... and where it was measured ahead of the fp32 kernels (batch 12, profiles/r04_reflect_patch.txt): 64 outputs or more (half of a 64-wide
+    // tile idle: 0.086 against 0.075 ms at 48x160, 64 -> 32), and for the adjoint the 24x80 maps and larger (12x40: level; 6x20, where every block
+    // is a border block and runs up to three times the MFMAs: 0.097 against 0.076 ms); mma = 3 (the parity tests) takes it on every shape
+    static const int refl_minpix = MCAV_KNOB_INT("MCAV_PATCH_REFLECT_MINPIX", 1000);
+    if (geo.refl && d->mma != 3 && (d->n_count < 64 || (geo.refl == 2 && d->Hd * d->Wd < refl_minpix))) return false;
     if (d->C2 != 0 || d->up1 || d->pool || d->w_upmerge) return false;
     if (d->C1 % 32 != 0 || d->Kp != d->C1 || d->Hd != d->Hs || d->Wd != d->Ws || d->n_count < 32) return false;
     if (d->groups > 1 && d->B % d->groups != 0) return false;
@@ -1121,10 +1204,10 @@ static int patch2_plan(const mcav_igemm_desc* d, PatchGeo& geo, int& bn) {
     if (!d || d->mma < 2) return 0;                                   // (the split form; plain bf16 keeps the first kernel)
     if (!enabled && !((d->tile >> 14) & 3)) return 0;
     PatchGeo g1;
-    if (!patch_plan(d, g1)) return 0;
+    if (!patch_plan(d, g1) || g1.refl) return 0;                     // (reflection / its adjoint: the first kernel only)
     int th, tw;
     patch_block(d->Hd, d->Wd, 64, PatchCfg<1>::PIX, th, tw);
-    geo.TH = th; geo.TW = tw; geo.tmb = 1;
+    geo.TH = th; geo.TW = tw; geo.tmb = 1; geo.refl = 0;
     geo.tiles_y = (d->Hd + th - 1) / th;
     geo.tiles_x = (d->Wd + tw - 1) / tw;
     const long per_img = (long)geo.tiles_y * geo.tiles_x, nblk = d->B * per_img, ntiles = (d->n_count + 63) / 64;
@@ -1532,11 +1615,20 @@ int mcav_bf16_igemm(const mcav_igemm_desc* d, hipStream_t s) {
         // (more than 64 KB of dynamic LDS has to be allowed once per kernel)
         static const bool allowed = [] {
             return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)patch_lds_bytes<3, 2>()) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch_kernel<3, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)patch_lds_bytes<3, 2>()) == hipSuccess;
         }();
         const int grid = p.mtiles * p.ntiles;
         const u16* w16 = reinterpret_cast<const u16*>(d->w16);
-        if (d->mma >= 2) {
+        if (geo.refl == 2) {                                          // (patch_plan: the split form only)
+            if (geo.tmb == 2) {
+                if (!allowed) return MCAV_E_LAUNCH;
+                timed_launch(conv3x3_patch_kernel<3, 2, true>, grid, dim3(256), patch_lds_bytes<3, 2>(), s, p, w16, geo);
+            } else {
+                timed_launch(conv3x3_patch_kernel<3, 1, true>, grid, dim3(256), patch_lds_bytes<3, 1>(), s, p, w16, geo);
+            }
+        } else if (d->mma >= 2) {
             if (geo.tmb == 2) {
                 if (!allowed) return MCAV_E_LAUNCH;
                 timed_launch(conv3x3_patch_kernel<3, 2>, grid, dim3(256), patch_lds_bytes<3, 2>(), s, p, w16, geo);
