@@ -1688,9 +1688,252 @@ MCAV_EXPORT int mcav_igemm_uses_bf16(const mcav_igemm_desc* d) {
     return bf16_tile_for(d, &refl) != 0;
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient on the patch (round 4)
+// dW[tap][ci][co] = sum over pixels p of x[p + tap - 1][ci] dy[p][co] for the 3x3 stride-1 layers, as an fp32 contraction on split operands
+// (section 4c's six plane products; ONE fp32 accumulator per output tile: the rounding pattern of the fp32-MFMA kernel it replaces, measured
+// level with it by tools/mfma_split_test.hip).  The reduction runs over PIXELS, so both MFMA operands want 8 consecutive pixels of one channel
+// per lane while NHWC memory -- and the patch image of the forward kernel -- keeps a pixel's channels together: gfx950's transposing LDS read
+// (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 columns of 16-bit elements and gets them column-major; each lane supplies the address
+// of one row piece) turns [pixel][32 channels] rows into exactly those operands, whatever the pixels are -- so the nine taps are nine row
+// offsets into ONE staged patch, as in conv3x3_patch_kernel, and a source element is fetched and split once per block instead of once per tap.
+// A workgroup = (pixel split, 64 input x 64 output channels), twelve wavefronts (three per SIMD, one workgroup per CU): wavefront (ky, ci half,
+// co half) owns the three 32 x 32 tiles of filter row ky.  Per block of <= 64 pixels (the planner's TH x TW shapes): the (TH + 2) x (TW + 2)
+// source patch and the dy block, both as three bf16 planes, in a two-stage LDS ring (133 KB): block b + 1 is converted and stored while block
+// b is multiplied (72 MFMAs per wavefront, one barrier per block), block b + 2 is in flight in registers.  The partial filter of a workgroup
+// goes to the slab the fp32 kernels use ([split][Ktot + 1][slabN]; row Ktot = column sums of dy, an MFMA against ones), reduced by the same
+// batched presum / reduce launches in the same fixed order.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int WGP_PIX = 110;                       // patch pixels (PatchCfg<1>::PIX)
+constexpr int WGP_XS = 3 * WGP_PIX * 32;           // u16 elements: one 32-channel half of the patch, three planes
+constexpr int WGP_DS = 3 * 64 * 32;                // ... of the dy block
+constexpr int WGP_STAGE = 2 * WGP_XS + 2 * WGP_DS; // one ring stage: 33 408 elements = 66 816 bytes
+constexpr int WGP_THREADS = 768;
+constexpr size_t wgrad_patch_lds_bytes() { return sizeof(u16) * 2 * (size_t)WGP_STAGE; }
+
+// timing experiments only, WRONG results (make variant FLAGS=-DMCAV_WGP_DIAG=n): 1 no MFMAs, 2 no staging in the loop, 4 no slab stores
+#ifndef MCAV_WGP_DIAG
+#define MCAV_WGP_DIAG 0
+#endif
+
+__device__ __forceinline__ bf16x8 tr_frag(const u16* lo4, const u16* hi4) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lo4);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)hi4);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    u16* const lds = reinterpret_cast<u16*>(s_raw);
+    constexpr int diag = MCAV_WGP_DIAG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ky = wave >> 2, ci_sub = (wave >> 1) & 1, co_sub = wave & 1;
+    const int ct_ci = p.Kp >> 6, ctiles = ct_ci * p.pct_co;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = lid % ctiles, split = lid / ctiles;
+    const int ci0 = (ct / p.pct_co) * 64, co0 = (ct % p.pct_co) * 64;
+    const int b_begin = split * p.pbps, b_end = min(p.pnblocks, b_begin + p.pbps);
+    const GatherSrc& g = p.g;
+    const int TH = p.pTH, TW = p.pTW, PW = TW + 2, PH = TH + 2, npix = TH * TW;
+    const int per_img = p.ptiles_y * p.ptiles_x;
+    const float rcp_pw = 1.0f / (float)PW, rcp_tw = 1.0f / (float)TW;
+
+    // staging: item = (pixel, 4 channels); the patch has 110 x 16 of them, the dy block 64 x 16
+    int xpy[3], xpx[3];                             // patch pixel -> (row, column) of the patch; -1: no such item / pixel
+    unsigned xdst[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int item = tid + WGP_THREADS * j, pp = item >> 4, c4 = item & 15;
+        const int ppy = small_div(pp, rcp_pw);
+        const bool ok = pp < PH * PW && pp < WGP_PIX;
+        xpy[j] = ok ? ppy : -1;
+        xpx[j] = pp - ppy * PW;
+        xdst[j] = (unsigned)((c4 >> 3) * WGP_XS + pp * 32 + (c4 & 7) * 4);
+    }
+    int dpy[2], dpx[2];
+    unsigned ddst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int item = tid + WGP_THREADS * j, k = item >> 4, c4 = item & 15;
+        const int py = small_div(k, rcp_tw);
+        const bool ok = item < 64 * 16 && k < npix && co0 + c4 * 4 < p.CoutLoad;
+        dpy[j] = ok ? py : -1;
+        dpx[j] = k - py * TW;
+        ddst[j] = (unsigned)(2 * WGP_XS + (c4 >> 3) * WGP_DS + k * 32 + (c4 & 7) * 4);
+    }
+    const unsigned xch = (unsigned)((ci0 + (tid & 15) * 4) * 4), dch = (unsigned)((p.dy_choff + co0 + (tid & 15) * 4) * 4);
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(g.x1, (unsigned)((size_t)g.B * g.Hs * g.Ws * g.C1 * 4));
+    const __amdgpu_buffer_rsrc_t rsd = make_rsrc(p.dy, (unsigned)((size_t)g.B * p.Hd * p.Wd * p.Cdy * 4));
+
+    f32x4 rx[3], rd[2];
+    auto load_block = [&](int blk) {
+        const int img = blk / per_img, tr = blk - img * per_img;
+        const int tyi = tr / p.ptiles_x;
+        const int ty0 = tyi * TH, tx0 = (tr - tyi * p.ptiles_x) * TW;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int y = ty0 - 1 + xpy[j], x = tx0 - 1 + xpx[j];
+            if (p.prefl) {                          // reflection padding: the ring of the map is its row / column 1, H - 2 / W - 2
+                y = y < 0 ? -y : (y >= g.Hs ? 2 * g.Hs - 2 - y : y);
+                x = x < 0 ? -x : (x >= g.Ws ? 2 * g.Ws - 2 - x : x);
+            }
+            const bool ok = xpy[j] >= 0 && (unsigned)y < (unsigned)g.Hs && (unsigned)x < (unsigned)g.Ws;
+            rx[j] = buf_load4s(rsx, ok ? (unsigned)(((img * g.Hs + y) * g.Ws + x) * g.C1 * 4) + xch : OOB, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int y = ty0 + dpy[j], x = tx0 + dpx[j];
+            const bool ok = dpy[j] >= 0 && y < p.Hd && x < p.Wd;
+            rd[j] = buf_load4s(rsd, ok ? (unsigned)(((img * p.Hd + y) * p.Wd + x) * p.Cdy * 4) + dch : OOB, 0);
+        }
+    };
+    auto split_store = [&](u16* dst, int plane_stride, const f32x4& v) {
+        const bf16x4 h = __builtin_convertvector(v, bf16x4);
+        const f32x4 r1 = v - __builtin_convertvector(h, f32x4);               // exact
+        const bf16x4 m = __builtin_convertvector(r1, bf16x4);
+        const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);              // exact
+        *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, h);
+        *reinterpret_cast<u32x2*>(dst + plane_stride) = __builtin_bit_cast(u32x2, m);
+        *reinterpret_cast<u32x2*>(dst + 2 * plane_stride) = pack_bf16x4(r2);
+    };
+    auto store_block = [&](int stage) {
+        u16* const base = lds + stage * WGP_STAGE;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (tid + WGP_THREADS * j < WGP_PIX * 16) split_store(base + xdst[j], WGP_PIX * 32, rx[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (tid + WGP_THREADS * j < 64 * 16) split_store(base + ddst[j], 64 * 32, rd[j]);
+    };
+
+    // operand addresses of this lane (elements, stage 0): lane 4q + c of a 16-lane group supplies row q, columns 4c .. 4c + 3 of the group's
+    // 4 x 16 block and receives column (lane & 15), rows 0 .. 3: for the 32x32x16 operands group g covers channels 16 (g & 1) .. + 15 and
+    // pixels 8 (g >> 1) + 4 h .. + 3 of the 16-pixel step (h = the first / second read of a fragment)
+    const int colel = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    unsigned xa[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = 16 * ks + 8 * (lane >> 5) + 4 * h + ((lane & 15) >> 2);
+            const int kk = k < npix ? k : 0;        // (pixels past the block: dy is zero there, any patch row will do)
+            const int py = small_div(kk, rcp_tw), px = kk - py * TW;
+            xa[ks][h] = (unsigned)(ci_sub * WGP_XS + ((py + ky) * PW + px) * 32 + colel);
+        }
+    const unsigned da = (unsigned)(2 * WGP_XS + co_sub * WGP_DS + (8 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + colel);
+
+    f32x16 acc[3], accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = 0.f; accb[r] = 0.f; }
+    const bool bias_wave = p.want_bias && ky == 0 && ci_sub == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    auto compute = [&](int stage) {
+        const u16* const base = lds + stage * WGP_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 b[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[q] = tr_frag(base + da + q * (64 * 32) + (16 * ks) * 32, base + da + q * (64 * 32) + (16 * ks + 4) * 32);
+            if (bias_wave) {
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b[2], accb, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b[1], accb, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b[0], accb, 0, 0, 0);
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                bf16x8 a[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[q] = tr_frag(base + xa[ks][0] + q * (WGP_PIX * 32) + kx * 32, base + xa[ks][1] + q * (WGP_PIX * 32) + kx * 32);
+                if (!(diag & 1)) {
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[kx], 0, 0, 0);
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[kx], 0, 0, 0);
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[kx], 0, 0, 0);
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[kx], 0, 0, 0);
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[kx], 0, 0, 0);
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[kx], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    if (b_begin < b_end) {
+        load_block(b_begin);
+        store_block(0);
+        if (b_begin + 1 < b_end) load_block(b_begin + 1);
+        __syncthreads();
+        int stage = 0;
+        for (int b = b_begin; b < b_end; ++b) {
+            compute(stage);
+            if (b + 1 < b_end && !(diag & 2)) {
+                store_block(stage ^ 1);             // (the registers hold block b + 1; the other stage was last read before the previous barrier)
+                if (b + 2 < b_end) load_block(b + 2);
+            }
+            __syncthreads();
+            stage ^= 1;
+        }
+    }
+    if (diag & 4) return;
+    // the workgroup's partial filter -> slab [split][Ktot + 1][slabN]: accumulator register r of lane l = row 8 (r >> 2) + 4 (l >> 5) + (r & 3), column l & 31
+    float* const slab = p.slab + (size_t)split * (p.Ktot + 1) * p.slabN;
+    const int co = co0 + co_sub * 32 + (lane & 31);
+    if (co < p.slabN) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + ci_sub * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                slab[(size_t)((ky * 3 + kx) * p.Kp + ci) * p.slabN + co] = acc[kx][r];
+            }
+        if (bias_wave && ct / p.pct_co == 0 && lane < 32) slab[(size_t)p.Ktot * p.slabN + co] = accb[0];
+    }
+}
+
+// Which weight gradients take wgrad3x3_patch_kernel: 3x3 stride 1, zero or reflection padding, one source of 64-channel multiples, >= 64 outputs.
+static bool wgrad_patch_plan(const mcav_wgrad_desc* d, WgradPlan& pl) {
+    static const int enabled = MCAV_KNOB_INT("MCAV_WGRAD_PATCH", 1);
+    static const int target = MCAV_KNOB_INT("MCAV_WGRAD_PATCH_WGS", 256);
+    if (!enabled || !d || d->mma < 2 || d->mma > 3 || d->upm || d->up1 || d->C2 != 0) return false;
+    if (d->mode != MCAV_G_DIRECT || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->sign != 1 || d->offset != -1) return false;
+    if (d->pad_mode != MCAV_PAD_ZERO && d->pad_mode != MCAV_PAD_REFLECT) return false;
+    if (d->pad_mode == MCAV_PAD_REFLECT && (d->Hs < 2 || d->Ws < 2)) return false;
+    if (d->C1 != d->Kp || d->Cin != d->Kp || d->Kp % 64 != 0 || d->Cout < 64 || d->Hd != d->Hs || d->Wd != d->Ws) return false;
+    if ((d->Cdy & 3) || (d->dy_choff & 3)) return false;
+    mcav_wgrad_desc dd = *d;
+    dd.tile = 2;
+    if (!plan_wgrad(&dd, pl) || pl.use_halo || pl.use_stem) return false;
+    WgradParams& p = pl.p;
+    if ((p.CoutLoad & 3) != 0) return false;
+    int th, tw;
+    patch_block(d->Hd, d->Wd, 64, WGP_PIX, th, tw);
+    p.patch = 1; p.split_planes = 1;
+    p.pTH = th; p.pTW = tw;
+    p.ptiles_y = (d->Hd + th - 1) / th; p.ptiles_x = (d->Wd + tw - 1) / tw;
+    p.prefl = d->pad_mode == MCAV_PAD_REFLECT;
+    p.pnblocks = d->B * p.ptiles_y * p.ptiles_x;
+    p.pct_co = (d->Cout + 63) / 64;
+    const int ctiles = (d->Kp / 64) * p.pct_co;
+    int splits = target / ctiles;                                     // one workgroup per CU
+    if (splits < 1) splits = 1;
+    if (splits > p.pnblocks) splits = p.pnblocks;
+    p.pbps = (p.pnblocks + splits - 1) / splits;
+    p.splits = (p.pnblocks + p.pbps - 1) / p.pbps;
+    pl.use_tab = false;
+    pl.slab_bytes = align_up(sizeof(float) * (size_t)p.splits * (p.Ktot + 1) * p.slabN, 256);
+    pl.groups = p.splits > 8 ? 8 : 0;
+    pl.per_group = pl.groups ? (p.splits + pl.groups - 1) / pl.groups : 0;
+    if (pl.groups) pl.groups = (p.splits + pl.per_group - 1) / pl.per_group;
+    pl.pre_bytes = align_up(sizeof(float) * (size_t)pl.groups * (p.Ktot + 1) * p.slabN, 256);
+    return true;
+}
+
 // Plans the bf16 weight-gradient launch into pl (splits over 64-pixel K-tiles, table chunking); false = not eligible.
 bool mcav_bf16_wgrad_plan(const mcav_wgrad_desc* d, WgradPlan& pl) {
     if (!d || (d->mma < 1 || d->mma > 3) || d->upm) return false;
+    if (wgrad_patch_plan(d, pl)) return true;
+    if (d->mma == 2) return false;                                    // mma = 2: the split form where it is ahead (the patch kernel), else fp32 MFMA
     if (d->mode != MCAV_G_DIRECT || d->Kp % 16 != 0 || d->C1 + d->C2 != d->Kp || d->Cin != d->Kp) return false;
     if ((d->C1 & 15) || (d->C2 & 15) || d->Cout < 32 || (d->Cdy & 3) || (d->dy_choff & 3)) return false;
     mcav_wgrad_desc dd = *d;
@@ -1780,6 +2023,13 @@ MCAV_EXPORT int mcav_f32_to_bf16(const float* src, void* dst_bf16, size_t n, voi
 }
 
 void mcav_bf16_wgrad_launch(const WgradParams& p, hipStream_t s) {
+    if (p.patch) {
+        static const bool allowed = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)wgrad_patch_lds_bytes()) == hipSuccess;
+        (void)allowed;                                                // (refused: the launch itself fails and launch_status() reports it)
+        timed_launch(wgrad3x3_patch_kernel, p.splits * (p.Kp / 64) * p.pct_co, dim3(WGP_THREADS), wgrad_patch_lds_bytes(), s, p);
+        return;
+    }
     if (p.split_planes) timed_launch(wgrad_bf16_kernel<3>, p.splits * p.mtiles * p.ntiles, dim3(256), 0, s, p);
     else timed_launch(wgrad_bf16_kernel<1>, p.splits * p.mtiles * p.ntiles, dim3(256), 0, s, p);
 }

@@ -2045,7 +2045,7 @@ bool plan_wgrad(const mcav_wgrad_desc* d, WgradPlan& pl) {
     if ((long)d->B * d->Hs * d->Ws * (d->C1 > d->C2 ? d->C1 : d->C2) * 4 >= 0x7fffffffL || M * d->Cdy * 4 >= 0x7fffffffL) return false;
     p.Mpix = (int)M;
     p.slabN = round_up(d->Cout, 16);
-    p.upm = 0; p.Hf = d->Hd; p.Wf = d->Wd;
+    p.upm = 0; p.Hf = d->Hd; p.Wf = d->Wd; p.patch = 0; p.split_planes = 0;
     if (d->upm) {      // merged-tap upsample half: 16 (class, merged tap) x Kp rows, reduction over the low-resolution pixels
         if (d->mode != MCAV_G_DIRECT || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->sign != 1 || d->offset != -1 || d->pad_mode != MCAV_PAD_REFLECT ||
             !d->up1 || d->C2 != 0 || d->Hd != d->Hs || d->Wd != d->Ws || (d->Hd & 1) || (d->Wd & 1) || d->dbias || d->Kp != d->C1 || (d->C1 & 15) ||

@@ -347,6 +347,9 @@ struct WgradParams {
     int upm;                       // merged-tap upsample (mcav_wgrad_desc.upm): rows = 16 (class, merged tap) x Kp, pixels = LOW-resolution ones
     int Hf, Wf;                    // upm: full-resolution size of dy (Hd, Wd hold the low-resolution one)
     int split_planes;              // conv_bf16.hip: 1 = the fp32 contraction on three bf16 planes per operand (mcav_wgrad_desc.mma = 2)
+    // conv_bf16.hip, wgrad3x3_patch_kernel (patch = 1): pixel blocks of TH x TW (<= 64 pixels) of one image, `bps` consecutive blocks per split,
+    // workgroup = (split, 64 input x 64 output channels)
+    int patch, pTH, pTW, ptiles_y, ptiles_x, prefl, pnblocks, pbps, pct_co;
 };
 
 constexpr int KP = 32;   // pixels per K-tile of the wgrad GEMM

@@ -377,7 +377,8 @@ class ConvSpec:
         return self._upa16
 
 
-# MMA_SPLIT weight gradients: 1 = on the split kernel (wgrad_bf16_kernel<3>), 0 = on the fp32-MFMA kernel (both are fp32 results)
+# MMA_SPLIT weight gradients: 1 = every launch the bf16 kernels cover on the split kernels (wgrad_bf16_kernel<3>); 0 = the patch kernel where it
+# applies, the fp32-MFMA kernel elsewhere (all are fp32 results)
 SPLIT_WGRAD = _os.environ.get("MCAV_SPLIT_WGRAD", "0") != "0"
 SPLIT_NAMES = ("fp32-split", "fp32_split", "f32s", "fp32s")
 MFMA32_NAMES = ("fp32-mfma", "fp32_mfma", "f32-mfma")
@@ -602,7 +603,9 @@ def conv_wgrad(spec, x1, dy, x2=None, up1=False, tile=0):
     d.Cout, d.Cin = spec.cout, spec.cin
     d.dw_oihw, d.accumulate, d.dbias = P(gw), 1, P(gb)
     d.tile = tile
-    d.mma = spec.mma if (spec.mma in (MMA_BF16, MMA_SPLIT_ALL) or (spec.mma == MMA_SPLIT and SPLIT_WGRAD)) else 0
+    # MMA_SPLIT: the library takes the split form where it is ahead (wgrad3x3_patch_kernel: single-source 3x3 stride-1 layers of 64-channel
+    # multiples) and the fp32 MFMA kernels elsewhere; MCAV_SPLIT_WGRAD=1 = the split form on every launch the bf16 kernels cover
+    d.mma = MMA_SPLIT_ALL if (spec.mma == MMA_SPLIT and SPLIT_WGRAD) else (spec.mma if spec.mma in (MMA_BF16, MMA_SPLIT, MMA_SPLIT_ALL) else 0)
     bf16 = bool(d.mma and L.lib().mcav_wgrad_uses_bf16(ctypes.byref(d)))
     flops = 2.0 * B * dy.shape[1] * dy.shape[2] * spec.cout * spec.cin * spec.kh * spec.kw
     tag = "pix=%d Cout=%d Ktot=%dx%d s%d" % (B * dy.shape[1] * dy.shape[2], spec.cout, spec.cin, spec.kh * spec.kw, spec.stride)
