@@ -121,15 +121,18 @@ def test_split_batchnorm_statistics_epilogue_and_groups(B, H, W):
         assert rel_err(s[1], (part ** 2).sum((0, 2, 3))) < 2e-6
 
 
-def test_split_decoder_level_fused_upsample_concat():
+@pytest.mark.parametrize("mode,Cout", [("all", 64), ("default", 64), ("default", 32)])
+def test_split_decoder_level_fused_upsample_concat(mode, Cout):
+    """A decoder level conv(cat(up2(a), skip)).  "all": every launch on the split kernels; "default": mma = 2 as the networks run it -- the weight
+    gradient as the skip half on the patch kernel (32 outputs: its narrow form) + the upsampled half in merged-tap form on the fp32 MFMA."""
     from mcav import nn as N
     g = torch.Generator().manual_seed(6)
-    B, h, w_, C1, C2, Cout = 2, 6, 10, 64, 64, 64
+    B, h, w_, C1, C2 = 2, 6, 10, 64, 64
     a = torch.randn(B, C1, h, w_, generator=g)
     skip = torch.randn(B, C2, 2 * h, 2 * w_, generator=g)
     wt = torch.randn(Cout, C1 + C2, 3, 3, generator=g) * 0.05
     bs = 0.1 * torch.randn(Cout, generator=g)
-    spec = spec_of(wt, bs, 1, 1, 1, N.MMA_SPLIT_ALL)
+    spec = spec_of(wt, bs, 1, 1, 1, N.MMA_SPLIT_ALL if mode == "all" else N.MMA_SPLIT)
     ar, sr, wr = a.double().requires_grad_(), skip.double().requires_grad_(), wt.double().requires_grad_()
     xcat = torch.cat([F.interpolate(ar, scale_factor=2, mode="nearest"), sr], 1)
     pre = F.conv2d(F.pad(xcat, (1, 1, 1, 1), mode="reflect"), wr, bs.double())
@@ -139,6 +142,7 @@ def test_split_decoder_level_fused_upsample_concat():
     assert rel_err(nchw(got), F.elu(pre)) < 2e-6
     N.conv_wgrad(spec, nhwc(a), nhwc(dy), x2=nhwc(skip), up1=True)
     assert rel_err(spec.weight.grad, wr.grad) < 2e-6
+    assert rel_err(spec.bias.grad, dy.double().sum((0, 2, 3))) < 2e-6
     dskip = N.conv_dgrad(spec, nhwc(dy), (2 * h, 2 * w_), n_begin=C1, n_count=C2)
     assert rel_err(nchw(dskip), sr.grad) < 2e-6
 
@@ -312,3 +316,40 @@ def test_second_patch_kernel_matches_float64_as_the_first_one_does(case, tile_bi
     for es, ef in zip(errs["second"][:3], errs["first"][:3]):
         assert es < 3e-6 and no_worse(es, ef), errs
     assert errs["second"][3] < 3e-5 and errs["second"][4] < 3e-6, errs
+
+
+@pytest.mark.parametrize("case", [(4, 48, 160, 64, 64, 0), (2, 24, 80, 128, 128, 1), (3, 7, 21, 64, 128, 1), (24, 6, 20, 128, 64, 0), (1, 12, 40, 64, 72, 0),
+                                  (4, 24, 80, 64, 32, 1)])
+def test_default_mode_weight_gradient_takes_the_patch_kernel_and_matches_float64(case):
+    """Round 4: under the DEFAULT mode (mcav_wgrad_desc.mma = 2) the weight gradients of the single-source 3x3 stride-1 layers with 64-channel
+    multiples run wgrad3x3_patch_kernel (transposing LDS reads over the staged patch, six plane products in one fp32 accumulator); everything
+    else stays on the fp32 MFMA kernels.  Against float64 on the unrounded operands the result is as close as the fp32 kernel's: zero and
+    reflection padding, blocks of several shapes (4 x 16, 3 x 20 with a ragged map, 6 x 10), 24 images, a Cout that is no multiple of 64, 32
+    outputs (the narrow form: wavefront pairs share a block's pixel steps), bias gradient (the MFMA against ones) and accumulation into an existing gradient."""
+    from mcav import nn as N
+    B, H, W, Cin, Cout, pad_mode = case
+    g = torch.Generator().manual_seed(1234 + H)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(1.5 * torch.randn(1, Cin, 1, 1, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    b = 0.1 * torch.randn(Cout, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g) * torch.exp(1.5 * torch.randn(1, Cout, 1, 1, generator=g))
+    wr = w.double().requires_grad_()
+    ref_conv64(x.double(), wr, None, 1, 1, pad_mode).backward(dy.double())
+    want_b = dy.double().sum((0, 2, 3))
+    errs, rms = {}, {}
+    for name, mma in (("fp32", N.MMA_FP32), ("split", N.MMA_SPLIT)):
+        spec = spec_of(w, b, 1, 1, pad_mode, mma)
+        N.conv_wgrad(spec, nhwc(x), nhwc(dy))
+        assert N.LAST_WGRAD_PLANES == (6 if mma == N.MMA_SPLIT else 0), "the launch did not take the expected kernel"
+        g1 = spec.weight.grad.clone()
+        N.conv_wgrad(spec, nhwc(x), nhwc(dy))                # accumulates
+        errs[name] = (rel_err(g1, wr.grad), rel_err(spec.weight.grad, 2 * wr.grad), rel_err(spec.bias.grad, 2 * want_b))
+        rms[name] = rms_err(g1, wr.grad)
+    print("wgrad %s: split %.2e (rms %.2e) / fp32 %.2e (rms %.2e); bias %.2e / %.2e" %
+          (case, errs["split"][0], rms["split"], errs["fp32"][0], rms["fp32"], errs["split"][2], errs["fp32"][2]))
+    assert all(e < 3e-6 for e in errs["split"]), errs
+    assert no_worse(errs["split"][0], errs["fp32"][0]) or rms["split"] <= 1.25 * rms["fp32"], (errs, rms)
+    # ... and a shape the patch kernel does not cover (32 input channels) stays on the fp32 MFMA kernel under the same mode
+    spec = spec_of(torch.randn(64, 32, 3, 3, generator=g) * 0.05, None, 1, 1, 0, N.MMA_SPLIT)
+    N.conv_wgrad(spec, torch.randn(2, 12, 20, 32, generator=g).to(DEV), torch.randn(2, 12, 20, 64, generator=g).to(DEV))
+    assert N.LAST_WGRAD_PLANES == 0

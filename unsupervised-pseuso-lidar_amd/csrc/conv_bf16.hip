@@ -1726,8 +1726,12 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     u16* const lds = reinterpret_cast<u16*>(s_raw);
     constexpr int diag = MCAV_WGP_DIAG;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ky = wave >> 2, ci_sub = (wave >> 1) & 1, co_sub = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ky = wave >> 2, ci_sub = (wave >> 1) & 1, half = wave & 1;
+    // 32 outputs or fewer (pnarrow): one 32-wide output tile, and the wavefront pairs share a block's four 16-pixel steps instead -- each half a
+    // slab split of its own (the slab then holds 2 x the pixel splits)
+    const bool narrow = p.pnarrow != 0;
+    const int co_sub = narrow ? 0 : half, ks0 = narrow ? 2 * half : 0, nks = narrow ? 2 : 4;
     const int ct_ci = p.Kp >> 6, ctiles = ct_ci * p.pct_co;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int ct = lid % ctiles, split = lid / ctiles;
@@ -1810,17 +1814,17 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
     // 4 x 16 block and receives column (lane & 15), rows 0 .. 3: for the 32x32x16 operands group g covers channels 16 (g & 1) .. + 15 and
     // pixels 8 (g >> 1) + 4 h .. + 3 of the 16-pixel step (h = the first / second read of a fragment)
     const int colel = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-    unsigned xa[4][2];
+    unsigned xa[4][2];                              // step i of this wavefront = the block's 16-pixel step ks0 + i
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int k = 16 * ks + 8 * (lane >> 5) + 4 * h + ((lane & 15) >> 2);
+            const int k = 16 * (ks0 + ks) + 8 * (lane >> 5) + 4 * h + ((lane & 15) >> 2);
             const int kk = k < npix ? k : 0;        // (pixels past the block: dy is zero there, any patch row will do)
             const int py = small_div(kk, rcp_tw), px = kk - py * TW;
             xa[ks][h] = (unsigned)(ci_sub * WGP_XS + ((py + ky) * PW + px) * 32 + colel);
         }
-    const unsigned da = (unsigned)(2 * WGP_XS + co_sub * WGP_DS + (8 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + colel);
+    const unsigned da = (unsigned)(2 * WGP_XS + co_sub * WGP_DS + (16 * ks0 + 8 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + colel);
 
     f32x16 acc[3], accb;
 #pragma unroll
@@ -1834,6 +1838,7 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
         const u16* const base = lds + stage * WGP_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            if (ks >= nks) break;
             bf16x8 b[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) b[q] = tr_frag(base + da + q * (64 * 32) + (16 * ks) * 32, base + da + q * (64 * 32) + (16 * ks + 4) * 32);
@@ -1877,7 +1882,7 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
     }
     if (diag & 4) return;
     // the workgroup's partial filter -> slab [split][Ktot + 1][slabN]: accumulator register r of lane l = row 8 (r >> 2) + 4 (l >> 5) + (r & 3), column l & 31
-    float* const slab = p.slab + (size_t)split * (p.Ktot + 1) * p.slabN;
+    float* const slab = p.slab + (size_t)(narrow ? 2 * split + half : split) * (p.Ktot + 1) * p.slabN;
     const int co = co0 + co_sub * 32 + (lane & 31);
     if (co < p.slabN) {
 #pragma unroll
@@ -1899,7 +1904,8 @@ static bool wgrad_patch_plan(const mcav_wgrad_desc* d, WgradPlan& pl) {
     if (d->mode != MCAV_G_DIRECT || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->sign != 1 || d->offset != -1) return false;
     if (d->pad_mode != MCAV_PAD_ZERO && d->pad_mode != MCAV_PAD_REFLECT) return false;
     if (d->pad_mode == MCAV_PAD_REFLECT && (d->Hs < 2 || d->Ws < 2)) return false;
-    if (d->C1 != d->Kp || d->Cin != d->Kp || d->Kp % 64 != 0 || d->Cout < 64 || d->Hd != d->Hs || d->Wd != d->Ws) return false;
+    if (d->C1 != d->Kp || d->Cin != d->Kp || d->Kp % 64 != 0 || d->Cout < 32 || d->Hd != d->Hs || d->Wd != d->Ws) return false;
+    if (d->Cout < 64 && d->Cout != 32) return false;                  // (32 outputs: the narrow form; 33 .. 63 would leave half of a 64-wide tile idle)
     if ((d->Cdy & 3) || (d->dy_choff & 3)) return false;
     mcav_wgrad_desc dd = *d;
     dd.tile = 2;
@@ -1914,12 +1920,13 @@ static bool wgrad_patch_plan(const mcav_wgrad_desc* d, WgradPlan& pl) {
     p.prefl = d->pad_mode == MCAV_PAD_REFLECT;
     p.pnblocks = d->B * p.ptiles_y * p.ptiles_x;
     p.pct_co = (d->Cout + 63) / 64;
+    p.pnarrow = d->Cout <= 32;
     const int ctiles = (d->Kp / 64) * p.pct_co;
     int splits = target / ctiles;                                     // one workgroup per CU
     if (splits < 1) splits = 1;
     if (splits > p.pnblocks) splits = p.pnblocks;
     p.pbps = (p.pnblocks + splits - 1) / splits;
-    p.splits = (p.pnblocks + p.pbps - 1) / p.pbps;
+    p.splits = (p.pnblocks + p.pbps - 1) / p.pbps * (p.pnarrow ? 2 : 1);      // slab splits
     pl.use_tab = false;
     pl.slab_bytes = align_up(sizeof(float) * (size_t)p.splits * (p.Ktot + 1) * p.slabN, 256);
     pl.groups = p.splits > 8 ? 8 : 0;
@@ -2027,7 +2034,7 @@ void mcav_bf16_wgrad_launch(const WgradParams& p, hipStream_t s) {
         static const bool allowed = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)wgrad_patch_lds_bytes()) == hipSuccess;
         (void)allowed;                                                // (refused: the launch itself fails and launch_status() reports it)
-        timed_launch(wgrad3x3_patch_kernel, p.splits * (p.Kp / 64) * p.pct_co, dim3(WGP_THREADS), wgrad_patch_lds_bytes(), s, p);
+        timed_launch(wgrad3x3_patch_kernel, (p.pnarrow ? p.splits / 2 : p.splits) * (p.Kp / 64) * p.pct_co, dim3(WGP_THREADS), wgrad_patch_lds_bytes(), s, p);
         return;
     }
     if (p.split_planes) timed_launch(wgrad_bf16_kernel<3>, p.splits * p.mtiles * p.ntiles, dim3(256), 0, s, p);

@@ -349,7 +349,7 @@ struct WgradParams {
     int split_planes;              // conv_bf16.hip: 1 = the fp32 contraction on three bf16 planes per operand (mcav_wgrad_desc.mma = 2)
     // conv_bf16.hip, wgrad3x3_patch_kernel (patch = 1): pixel blocks of TH x TW (<= 64 pixels) of one image, `bps` consecutive blocks per split,
     // workgroup = (split, 64 input x 64 output channels)
-    int patch, pTH, pTW, ptiles_y, ptiles_x, prefl, pnblocks, pbps, pct_co;
+    int patch, pTH, pTW, ptiles_y, ptiles_x, prefl, pnblocks, pbps, pct_co, pnarrow;
 };
 
 constexpr int KP = 32;   // pixels per K-tile of the wgrad GEMM

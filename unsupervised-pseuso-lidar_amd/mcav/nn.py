@@ -623,7 +623,8 @@ def conv_wgrad(spec, x1, dy, x2=None, up1=False, tile=0):
         return
     if (not bf16 and up1 and x2 is not None and spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad == 1 and spec.pad_mode == PAD_REFLECT
             and c1 % 16 == 0 and x2.shape[3] % 16 == 0 and Hs % 2 == 0 and Ws % 2 == 0 and not (tile >> 11) & 1
-            and (spec.cout >= 64 or (tile >> 12) & 1)):       # measured: 32 output channels are faster in one launch (bit 12 forces)
+            and (spec.cout >= 64 or (tile >> 12) & 1          # measured: 32 output channels are faster in one launch (bit 12 forces) ...
+                 or (d.mma >= MMA_SPLIT and spec.cout == 32 and x2.shape[3] % 64 == 0))):      # ... unless the skip half takes the patch kernel
         # two launches: the skip tensor's channels as an ordinary weight gradient, the upsampled map's in merged-tap form (mcav_conv.h)
         c2 = x2.shape[3]
         d.x1, d.x2, d.C1, d.C2, d.up1, d.Kp = P(x2), None, c2, 0, 0, up16(c2)
@@ -804,6 +805,9 @@ class _WgradBatch:
 WGRAD_BATCH = _WgradBatch()
 
 
+LAST_WGRAD_PLANES = 0
+
+
 def launch_wgrad(d, tensors, flops=0.0, tag="", executed=None):
     """mcav_wgrad for a filled descriptor (workspace handling + stream choice).  tensors: what the launch reads."""
     h = L.lib()
@@ -814,6 +818,10 @@ def launch_wgrad(d, tensors, flops=0.0, tag="", executed=None):
 
     dev = tensors[0].device
     planes = _planes(d) if (d.mma and h.mcav_wgrad_uses_bf16(ctypes.byref(d))) else 0
+    global LAST_WGRAD_PLANES
+    LAST_WGRAD_PLANES = planes                      # (tests: which pipe the last weight-gradient launch took -- 6: split form, 1: bf16, 0: fp32 MFMA)
+    if planes:
+        tag += _pipe_tag(d)
     defer = WGRAD_BATCH.enabled and dev.type == "cuda" and WGRAD_SIDE._note(torch.cuda.current_stream())
     if defer:
         # inside a backward pass: GEMM now, the slab reduction with its bucket (grads_ready / the end-of-backward join).  The descriptor is
