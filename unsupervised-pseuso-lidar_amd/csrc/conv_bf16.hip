@@ -1700,7 +1700,7 @@ MCAV_EXPORT int mcav_igemm_uses_bf16(const mcav_igemm_desc* d) {
 // co half) owns the three 32 x 32 tiles of filter row ky.  Per block of <= 64 pixels (the planner's TH x TW shapes): the (TH + 2) x (TW + 2)
 // source patch and the dy block, both as three bf16 planes, in a two-stage LDS ring (133 KB): block b + 1 is converted and stored while block
 // b is multiplied (72 MFMAs per wavefront, one barrier per block), block b + 2 is in flight in registers.  The partial filter of a workgroup
-// goes to the slab the fp32 kernels use ([split][Ktot + 1][slabN]; row Ktot = column sums of dy, an MFMA against ones), reduced by the same
+// goes to the slab the fp32 kernels use ([split][Ktot + 1][slabN]; row Ktot = column sums of dy, summed by the staging threads), reduced by the same
 // batched presum / reduce launches in the same fixed order.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -1711,7 +1711,8 @@ constexpr int WGP_STAGE = 2 * WGP_XS + 2 * WGP_DS; // one ring stage: 33 408 ele
 constexpr int WGP_THREADS = 768;
 constexpr size_t wgrad_patch_lds_bytes() { return sizeof(u16) * 2 * (size_t)WGP_STAGE; }
 
-// timing experiments only, WRONG results (make variant FLAGS=-DMCAV_WGP_DIAG=n): 1 no MFMAs, 2 no staging in the loop, 4 no slab stores
+// timing experiments only, WRONG results (make variant FLAGS=-DMCAV_WGP_DIAG=n): 1 no MFMAs, 2 no staging in the loop, 4 no slab stores, 8 no
+// barrier in the loop, 16 no conversion arithmetic in the staging (raw halves stored)
 #ifndef MCAV_WGP_DIAG
 #define MCAV_WGP_DIAG 0
 #endif
@@ -1722,6 +1723,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const u16* lo4, const u16* hi4) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+template <bool BIAS>                               // BIAS: the launch also wants the column sums of dy (one more accumulator in two wavefronts)
 __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     u16* const lds = reinterpret_cast<u16*>(s_raw);
@@ -1769,8 +1771,8 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
     const __amdgpu_buffer_rsrc_t rsx = make_rsrc(g.x1, (unsigned)((size_t)g.B * g.Hs * g.Ws * g.C1 * 4));
     const __amdgpu_buffer_rsrc_t rsd = make_rsrc(p.dy, (unsigned)((size_t)g.B * p.Hd * p.Wd * p.Cdy * 4));
 
-    f32x4 rx[3], rd[2];
-    auto load_block = [&](int blk) {
+    f32x4 rx[3], rd[2], bsum = {0.f, 0.f, 0.f, 0.f};
+    auto load_x = [&](int blk) {
         const int img = blk / per_img, tr = blk - img * per_img;
         const int tyi = tr / p.ptiles_x;
         const int ty0 = tyi * TH, tx0 = (tr - tyi * p.ptiles_x) * TW;
@@ -1784,6 +1786,11 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
             const bool ok = xpy[j] >= 0 && (unsigned)y < (unsigned)g.Hs && (unsigned)x < (unsigned)g.Ws;
             rx[j] = buf_load4s(rsx, ok ? (unsigned)(((img * g.Hs + y) * g.Ws + x) * g.C1 * 4) + xch : OOB, 0);
         }
+    };
+    auto load_d = [&](int blk) {
+        const int img = blk / per_img, tr = blk - img * per_img;
+        const int tyi = tr / p.ptiles_x;
+        const int ty0 = tyi * TH, tx0 = (tr - tyi * p.ptiles_x) * TW;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int y = ty0 + dpy[j], x = tx0 + dpx[j];
@@ -1791,7 +1798,15 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
             rd[j] = buf_load4s(rsd, ok ? (unsigned)(((img * p.Hd + y) * p.Wd + x) * p.Cdy * 4) + dch : OOB, 0);
         }
     };
+    auto load_block = [&](int blk) { load_x(blk); load_d(blk); };
     auto split_store = [&](u16* dst, int plane_stride, const f32x4& v) {
+        if (diag & 16) {
+            const u32x2 raw = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[2])};
+            *reinterpret_cast<u32x2*>(dst) = raw;
+            *reinterpret_cast<u32x2*>(dst + plane_stride) = raw;
+            *reinterpret_cast<u32x2*>(dst + 2 * plane_stride) = raw;
+            return;
+        }
         const bf16x4 h = __builtin_convertvector(v, bf16x4);
         const f32x4 r1 = v - __builtin_convertvector(h, f32x4);               // exact
         const bf16x4 m = __builtin_convertvector(r1, bf16x4);
@@ -1800,14 +1815,32 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
         *reinterpret_cast<u32x2*>(dst + plane_stride) = __builtin_bit_cast(u32x2, m);
         *reinterpret_cast<u32x2*>(dst + 2 * plane_stride) = pack_bf16x4(r2);
     };
-    auto store_block = [&](int stage) {
+    // the staged block goes to LDS in five pieces (three patch items, two dy items per thread)
+    auto store_piece = [&](int stage, auto piece) {
+        constexpr int i = decltype(piece)::value;
         u16* const base = lds + stage * WGP_STAGE;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            if (tid + WGP_THREADS * j < WGP_PIX * 16) split_store(base + xdst[j], WGP_PIX * 32, rx[j]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (tid + WGP_THREADS * j < 64 * 16) split_store(base + ddst[j], 64 * 32, rd[j]);
+        if constexpr (i < 3) {
+            if (tid + WGP_THREADS * i < WGP_PIX * 16) split_store(base + xdst[i], WGP_PIX * 32, rx[i]);
+        } else {
+            if (tid + WGP_THREADS * (i - 3) < 64 * 16) split_store(base + ddst[i - 3], 64 * 32, rd[i - 3]);
+            if constexpr (BIAS) bsum += rd[i - 3];    // column sums of dy (the bias gradient): this thread's pixels of its four channels (pixels past the map are zero)
+        }
+    };
+    auto store_piece_n = [&](int stage, int i) {       // (i is a constant after unrolling)
+        switch (i) {
+            case 0: store_piece(stage, std::integral_constant<int, 0>()); break;
+            case 1: store_piece(stage, std::integral_constant<int, 1>()); break;
+            case 2: store_piece(stage, std::integral_constant<int, 2>()); break;
+            case 3: store_piece(stage, std::integral_constant<int, 3>()); break;
+            default: store_piece(stage, std::integral_constant<int, 4>()); break;
+        }
+    };
+    auto store_block = [&](int stage) {
+        store_piece(stage, std::integral_constant<int, 0>());
+        store_piece(stage, std::integral_constant<int, 1>());
+        store_piece(stage, std::integral_constant<int, 2>());
+        store_piece(stage, std::integral_constant<int, 3>());
+        store_piece(stage, std::integral_constant<int, 4>());
     };
 
     // operand addresses of this lane (elements, stage 0): lane 4q + c of a 16-lane group supplies row q, columns 4c .. 4c + 3 of the group's
@@ -1826,41 +1859,58 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
         }
     const unsigned da = (unsigned)(2 * WGP_XS + co_sub * WGP_DS + (16 * ks0 + 8 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + colel);
 
-    f32x16 acc[3], accb;
+    f32x16 acc[3];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = 0.f; accb[r] = 0.f; }
-    const bool bias_wave = p.want_bias && ky == 0 && ci_sub == 0;
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = 0.f; }
 
-    auto compute = [&](int stage) {
+    // A block's steps (four 16-pixel steps x three taps of the wavefront's filter row; the narrow form: two x three), software-pipelined by hand:
+    // the fragments of step s + 1 are read while the six MFMAs of step s run, and the NEXT block's conversion and LDS stores (store_piece: the
+    // other ring stage) are spread over the steps instead of following them -- all twelve wavefronts run in phase between two barriers, so
+    // staging done after the multiply would find the MFMA pipe idle (measured: 5.7 us per block against 4.5 without any staging).
+    const int nsteps = 3 * nks;
+    auto compute = [&](int stage, bool more, int next2) {      // next2: block b + 2, or -1
         const u16* const base = lds + stage * WGP_STAGE;
+        bf16x8 a[2][3], b[2][3];
+        auto loadA = [&](int st, bf16x8 (&f)[3]) {
+            const int ks = st / 3, kx = st - 3 * ks;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks >= nks) break;
-            bf16x8 b[3];
+            for (int q = 0; q < 3; ++q) f[q] = tr_frag(base + xa[ks][0] + q * (WGP_PIX * 32) + kx * 32, base + xa[ks][1] + q * (WGP_PIX * 32) + kx * 32);
+        };
+        auto loadB = [&](int ks, bf16x8 (&f)[3]) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) b[q] = tr_frag(base + da + q * (64 * 32) + (16 * ks) * 32, base + da + q * (64 * 32) + (16 * ks + 4) * 32);
-            if (bias_wave) {
-                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b[2], accb, 0, 0, 0);
-                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b[1], accb, 0, 0, 0);
-                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, b[0], accb, 0, 0, 0);
+            for (int q = 0; q < 3; ++q) f[q] = tr_frag(base + da + q * (64 * 32) + (16 * ks) * 32, base + da + q * (64 * 32) + (16 * ks + 4) * 32);
+        };
+        loadB(0, b[0]);
+        loadA(0, a[0]);
+#pragma unroll
+        for (int st = 0; st < 12; ++st) {
+            if (st >= nsteps) break;
+            const int ks = st / 3, kx = st - 3 * ks;
+            if (st + 1 < nsteps) {
+                if ((st + 1) % 3 == 0) loadB((st + 1) / 3, b[((st + 1) / 3) & 1]);
+                loadA(st + 1, a[(st + 1) & 1]);
             }
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                bf16x8 a[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) a[q] = tr_frag(base + xa[ks][0] + q * (WGP_PIX * 32) + kx * 32, base + xa[ks][1] + q * (WGP_PIX * 32) + kx * 32);
-                if (!(diag & 1)) {
-                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[kx], 0, 0, 0);
-                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[kx], 0, 0, 0);
-                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[kx], 0, 0, 0);
-                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[kx], 0, 0, 0);
-                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[kx], 0, 0, 0);
-                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[kx], 0, 0, 0);
-                }
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8(&fa)[3] = a[st & 1];
+            const bf16x8(&fb)[3] = b[ks & 1];
+            if (!(diag & 1)) {
+                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc[kx], 0, 0, 0);
+                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], acc[kx], 0, 0, 0);
+                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc[kx], 0, 0, 0);
+                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[kx], 0, 0, 0);
+                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[kx], 0, 0, 0);
+                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[kx], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && !(diag & 2)) {              // a piece of block b + 1's staging behind this step's MFMAs: steps 1, 3, .. 9 (narrow: 0 .. 4);
+                const int pc = narrow ? (st < 5 ? st : -1) : (((st & 1) && st < 10) ? (st - 1) / 2 : -1);
+                if (pc >= 0) store_piece_n(stage ^ 1, pc);
+                // ... and block b + 2's loads as soon as their registers are free (half a block and more before their use: a load issued at the
+                // end of the block would be waited for at its first piece)
+                if (pc == 2 && next2 >= 0) load_x(next2);
+                if (pc == 4 && next2 >= 0) load_d(next2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -1871,12 +1921,8 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
         __syncthreads();
         int stage = 0;
         for (int b = b_begin; b < b_end; ++b) {
-            compute(stage);
-            if (b + 1 < b_end && !(diag & 2)) {
-                store_block(stage ^ 1);             // (the registers hold block b + 1; the other stage was last read before the previous barrier)
-                if (b + 2 < b_end) load_block(b + 2);
-            }
-            __syncthreads();
+            compute(stage, b + 1 < b_end, b + 2 < b_end ? b + 2 : -1);      // (stores block b + 1 from the registers into the other stage, last read before the previous barrier)
+            if (!(diag & 8)) __syncthreads();
             stage ^= 1;
         }
     }
@@ -1892,7 +1938,21 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
                 const int ci = ci0 + ci_sub * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
                 slab[(size_t)((ky * 3 + kx) * p.Kp + ci) * p.slabN + co] = acc[kx][r];
             }
-        if (bias_wave && ct / p.pct_co == 0 && lane < 32) slab[(size_t)p.Ktot * p.slabN + co] = accb[0];
+    }
+    if constexpr (BIAS) {
+        // slab row Ktot = the split's column sums of dy: the staging threads' sums (48 threads per group of four channels) through LDS -- the ring
+        // is free after the loop's last barrier.  One input-channel tile writes the row; the narrow form's second slab split gets zeros.
+        if (ct / p.pct_co != 0) return;
+        f32x4* const sb = reinterpret_cast<f32x4*>(s_raw);
+        sb[tid] = bsum;
+        __syncthreads();
+        if (tid < 64 && co0 + tid < p.slabN) {
+            float sum = 0.f;
+            for (int r = 0; r < WGP_THREADS / 16; ++r) sum += sb[r * 16 + (tid >> 2)][tid & 3];
+            float* const s0 = p.slab + (size_t)(narrow ? 2 * split : split) * (p.Ktot + 1) * p.slabN + (size_t)p.Ktot * p.slabN;
+            s0[co0 + tid] = sum;
+            if (narrow) s0[(size_t)(p.Ktot + 1) * p.slabN + co0 + tid] = 0.f;
+        }
     }
 }
 
@@ -2031,10 +2091,14 @@ MCAV_EXPORT int mcav_f32_to_bf16(const float* src, void* dst_bf16, size_t n, voi
 
 void mcav_bf16_wgrad_launch(const WgradParams& p, hipStream_t s) {
     if (p.patch) {
-        static const bool allowed = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        static const bool allowed = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_patch_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)wgrad_patch_lds_bytes()) == hipSuccess &&
+                                    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_patch_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)wgrad_patch_lds_bytes()) == hipSuccess;
         (void)allowed;                                                // (refused: the launch itself fails and launch_status() reports it)
-        timed_launch(wgrad3x3_patch_kernel, (p.pnarrow ? p.splits / 2 : p.splits) * (p.Kp / 64) * p.pct_co, dim3(WGP_THREADS), wgrad_patch_lds_bytes(), s, p);
+        const int grid = (p.pnarrow ? p.splits / 2 : p.splits) * (p.Kp / 64) * p.pct_co;
+        if (p.want_bias) timed_launch(wgrad3x3_patch_kernel<true>, grid, dim3(WGP_THREADS), wgrad_patch_lds_bytes(), s, p);
+        else timed_launch(wgrad3x3_patch_kernel<false>, grid, dim3(WGP_THREADS), wgrad_patch_lds_bytes(), s, p);
         return;
     }
     if (p.split_planes) timed_launch(wgrad_bf16_kernel<3>, p.splits * p.mtiles * p.ntiles, dim3(256), 0, s, p);
