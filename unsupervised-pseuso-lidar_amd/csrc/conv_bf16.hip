@@ -1705,11 +1705,13 @@ MCAV_EXPORT int mcav_igemm_uses_bf16(const mcav_igemm_desc* d) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 constexpr int WGP_PIX = 110;                       // patch pixels (PatchCfg<1>::PIX)
-constexpr int WGP_XS = 3 * WGP_PIX * 32;           // u16 elements: one 32-channel half of the patch, three planes
-constexpr int WGP_DS = 3 * 64 * 32;                // ... of the dy block
-constexpr int WGP_STAGE = 2 * WGP_XS + 2 * WGP_DS; // one ring stage: 33 408 elements = 66 816 bytes
 constexpr int WGP_THREADS = 768;
-constexpr size_t wgrad_patch_lds_bytes() { return sizeof(u16) * 2 * (size_t)WGP_STAGE; }
+template <int NS> struct WgpCfg {                  // NS planes per operand: 3 = the split fp32 form, 1 = plain bf16 (mcav_wgrad_desc.mma = 1)
+    static constexpr int XS = NS * WGP_PIX * 32;   // u16 elements: one 32-channel half of the patch
+    static constexpr int DS = NS * 64 * 32;        // ... of the dy block
+    static constexpr int STAGE = 2 * XS + 2 * DS;  // one ring stage: 33 408 elements = 66 816 bytes in the split form
+};
+template <int NS> constexpr size_t wgrad_patch_lds_bytes() { return sizeof(u16) * 2 * (size_t)WgpCfg<NS>::STAGE; }
 
 // timing experiments only, WRONG results (make variant FLAGS=-DMCAV_WGP_DIAG=n): 1 no MFMAs, 2 no staging in the loop, 4 no slab stores, 8 no
 // barrier in the loop, 16 no conversion arithmetic in the staging (raw halves stored)
@@ -1723,8 +1725,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const u16* lo4, const u16* hi4) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <bool BIAS>                               // BIAS: the launch also wants the column sums of dy (one more accumulator in two wavefronts)
+template <int NS, bool BIAS>                       // BIAS: the launch also wants the column sums of dy
 __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradParams p) {
+    constexpr int WGP_XS = WgpCfg<NS>::XS, WGP_DS = WgpCfg<NS>::DS, WGP_STAGE = WgpCfg<NS>::STAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     u16* const lds = reinterpret_cast<u16*>(s_raw);
     constexpr int diag = MCAV_WGP_DIAG;
@@ -1807,13 +1810,17 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
             *reinterpret_cast<u32x2*>(dst + 2 * plane_stride) = raw;
             return;
         }
-        const bf16x4 h = __builtin_convertvector(v, bf16x4);
-        const f32x4 r1 = v - __builtin_convertvector(h, f32x4);               // exact
-        const bf16x4 m = __builtin_convertvector(r1, bf16x4);
-        const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);              // exact
-        *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, h);
-        *reinterpret_cast<u32x2*>(dst + plane_stride) = __builtin_bit_cast(u32x2, m);
-        *reinterpret_cast<u32x2*>(dst + 2 * plane_stride) = pack_bf16x4(r2);
+        if constexpr (NS == 1) {
+            *reinterpret_cast<u32x2*>(dst) = pack_bf16x4(v);
+        } else {
+            const bf16x4 h = __builtin_convertvector(v, bf16x4);
+            const f32x4 r1 = v - __builtin_convertvector(h, f32x4);           // exact
+            const bf16x4 m = __builtin_convertvector(r1, bf16x4);
+            const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);          // exact
+            *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, h);
+            *reinterpret_cast<u32x2*>(dst + plane_stride) = __builtin_bit_cast(u32x2, m);
+            *reinterpret_cast<u32x2*>(dst + 2 * plane_stride) = pack_bf16x4(r2);
+        }
     };
     // the staged block goes to LDS in five pieces (three patch items, two dy items per thread)
     auto store_piece = [&](int stage, auto piece) {
@@ -1870,15 +1877,15 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
     const int nsteps = 3 * nks;
     auto compute = [&](int stage, bool more, int next2) {      // next2: block b + 2, or -1
         const u16* const base = lds + stage * WGP_STAGE;
-        bf16x8 a[2][3], b[2][3];
-        auto loadA = [&](int st, bf16x8 (&f)[3]) {
+        bf16x8 a[2][NS], b[2][NS];
+        auto loadA = [&](int st, bf16x8 (&f)[NS]) {
             const int ks = st / 3, kx = st - 3 * ks;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) f[q] = tr_frag(base + xa[ks][0] + q * (WGP_PIX * 32) + kx * 32, base + xa[ks][1] + q * (WGP_PIX * 32) + kx * 32);
+            for (int q = 0; q < NS; ++q) f[q] = tr_frag(base + xa[ks][0] + q * (WGP_PIX * 32) + kx * 32, base + xa[ks][1] + q * (WGP_PIX * 32) + kx * 32);
         };
-        auto loadB = [&](int ks, bf16x8 (&f)[3]) {
+        auto loadB = [&](int ks, bf16x8 (&f)[NS]) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) f[q] = tr_frag(base + da + q * (64 * 32) + (16 * ks) * 32, base + da + q * (64 * 32) + (16 * ks + 4) * 32);
+            for (int q = 0; q < NS; ++q) f[q] = tr_frag(base + da + q * (64 * 32) + (16 * ks) * 32, base + da + q * (64 * 32) + (16 * ks + 4) * 32);
         };
         loadB(0, b[0]);
         loadA(0, a[0]);
@@ -1891,15 +1898,19 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
                 loadA(st + 1, a[(st + 1) & 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            const bf16x8(&fa)[3] = a[st & 1];
-            const bf16x8(&fb)[3] = b[ks & 1];
+            const bf16x8(&fa)[NS] = a[st & 1];
+            const bf16x8(&fb)[NS] = b[ks & 1];
             if (!(diag & 1)) {
-                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc[kx], 0, 0, 0);
-                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], acc[kx], 0, 0, 0);
-                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc[kx], 0, 0, 0);
-                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[kx], 0, 0, 0);
-                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[kx], 0, 0, 0);
-                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[kx], 0, 0, 0);
+                if constexpr (NS == 1) {
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[kx], 0, 0, 0);
+                } else {
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc[kx], 0, 0, 0);
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], acc[kx], 0, 0, 0);
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc[kx], 0, 0, 0);
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[kx], 0, 0, 0);
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[kx], 0, 0, 0);
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[kx], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (more && !(diag & 2)) {              // a piece of block b + 1's staging behind this step's MFMAs: steps 1, 3, .. 9 (narrow: 0 .. 4);
@@ -1960,7 +1971,7 @@ __global__ __launch_bounds__(WGP_THREADS, 1) void wgrad3x3_patch_kernel(WgradPar
 static bool wgrad_patch_plan(const mcav_wgrad_desc* d, WgradPlan& pl) {
     static const int enabled = MCAV_KNOB_INT("MCAV_WGRAD_PATCH", 1);
     static const int target = MCAV_KNOB_INT("MCAV_WGRAD_PATCH_WGS", 256);
-    if (!enabled || !d || d->mma < 2 || d->mma > 3 || d->upm || d->up1 || d->C2 != 0) return false;
+    if (!enabled || !d || d->mma < 1 || d->mma > 3 || d->upm || d->up1 || d->C2 != 0) return false;
     if (d->mode != MCAV_G_DIRECT || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->sign != 1 || d->offset != -1) return false;
     if (d->pad_mode != MCAV_PAD_ZERO && d->pad_mode != MCAV_PAD_REFLECT) return false;
     if (d->pad_mode == MCAV_PAD_REFLECT && (d->Hs < 2 || d->Ws < 2)) return false;
@@ -1974,7 +1985,7 @@ static bool wgrad_patch_plan(const mcav_wgrad_desc* d, WgradPlan& pl) {
     if ((p.CoutLoad & 3) != 0) return false;
     int th, tw;
     patch_block(d->Hd, d->Wd, 64, WGP_PIX, th, tw);
-    p.patch = 1; p.split_planes = 1;
+    p.patch = 1; p.split_planes = d->mma >= 2;
     p.pTH = th; p.pTW = tw;
     p.ptiles_y = (d->Hd + th - 1) / th; p.ptiles_x = (d->Wd + tw - 1) / tw;
     p.prefl = d->pad_mode == MCAV_PAD_REFLECT;
@@ -2091,14 +2102,23 @@ MCAV_EXPORT int mcav_f32_to_bf16(const float* src, void* dst_bf16, size_t n, voi
 
 void mcav_bf16_wgrad_launch(const WgradParams& p, hipStream_t s) {
     if (p.patch) {
-        static const bool allowed = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_patch_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)wgrad_patch_lds_bytes()) == hipSuccess &&
-                                    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_patch_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)wgrad_patch_lds_bytes()) == hipSuccess;
+        static const bool allowed = [] {
+            bool ok = true;
+            ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_patch_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_patch_lds_bytes<3>()) == hipSuccess;
+            ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_patch_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_patch_lds_bytes<3>()) == hipSuccess;
+            ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_patch_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_patch_lds_bytes<1>()) == hipSuccess;
+            ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_patch_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wgrad_patch_lds_bytes<1>()) == hipSuccess;
+            return ok;
+        }();
         (void)allowed;                                                // (refused: the launch itself fails and launch_status() reports it)
         const int grid = (p.pnarrow ? p.splits / 2 : p.splits) * (p.Kp / 64) * p.pct_co;
-        if (p.want_bias) timed_launch(wgrad3x3_patch_kernel<true>, grid, dim3(WGP_THREADS), wgrad_patch_lds_bytes(), s, p);
-        else timed_launch(wgrad3x3_patch_kernel<false>, grid, dim3(WGP_THREADS), wgrad_patch_lds_bytes(), s, p);
+        if (p.split_planes) {
+            if (p.want_bias) timed_launch(wgrad3x3_patch_kernel<3, true>, grid, dim3(WGP_THREADS), wgrad_patch_lds_bytes<3>(), s, p);
+            else timed_launch(wgrad3x3_patch_kernel<3, false>, grid, dim3(WGP_THREADS), wgrad_patch_lds_bytes<3>(), s, p);
+        } else {
+            if (p.want_bias) timed_launch(wgrad3x3_patch_kernel<1, true>, grid, dim3(WGP_THREADS), wgrad_patch_lds_bytes<1>(), s, p);
+            else timed_launch(wgrad3x3_patch_kernel<1, false>, grid, dim3(WGP_THREADS), wgrad_patch_lds_bytes<1>(), s, p);
+        }
         return;
     }
     if (p.split_planes) timed_launch(wgrad_bf16_kernel<3>, p.splits * p.mtiles * p.ntiles, dim3(256), 0, s, p);
