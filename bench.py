@@ -48,7 +48,7 @@ def PROFILE_MODE(path):
     """Which --dtype a committed profile was taken in: rounds 1-3 ran every contraction on the fp32 MFMA by default (today's fp32-mfma)."""
     return "fp32" if os.path.basename(path) >= "r04" else "fp32-mfma"
 CONV_KERNELS = ("igemm_kernel", "igemm_tab_kernel", "igemm_bf16", "wgrad_kernel", "wgrad_tab_kernel", "wgrad_bf16", "conv3x3_halo", "conv3x3r_c1",
-                "stem7x7s2", "splitk_finish", "wgrad_reduce", "wgrad_presum", "patch3x3", "conv3x3_patch")
+                "stem7x7s2", "splitk_finish", "wgrad_reduce", "wgrad_presum", "patch3x3", "conv3x3_patch", "wgrad3x3_patch")
 
 
 def rocprof_conv_ms_per_step():

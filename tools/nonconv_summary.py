@@ -18,7 +18,7 @@ for r in rows:
         slab += ms
         conv += ms
         continue
-    if any(k in n for k in ("igemm", "wgrad_tab", "wgrad_kernel", "wgrad_bf16", "halo", "stem7x7", "conv3x3r", "conv3x3_patch", "splitk_finish")):
+    if any(k in n for k in ("igemm", "wgrad_tab", "wgrad_kernel", "wgrad_bf16", "wgrad3x3_patch", "halo", "stem7x7", "conv3x3r", "conv3x3_patch", "splitk_finish")):
         conv += ms
         continue
     other += ms
