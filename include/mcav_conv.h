@@ -135,7 +135,12 @@ typedef struct mcav_wgrad_desc {
     int upm, Cin_total, ci_offset;
     int mma;                /* 1: both operands rounded to bf16, reduction over pixels on the bf16 MFMA, fp32 slab / gradient (launches with
                              * >= 32 output channels and 16-channel-aligned sources; others run the fp32 kernels).
-                             * 2 / 3: the same launches as an fp32 contraction on three bf16 planes per operand (mcav_igemm_desc.mma = 2) */
+                             * 2: an fp32 contraction on three bf16 planes per operand (mcav_igemm_desc.mma = 2) WHERE THAT FORM IS AHEAD: the
+                             *    single-source 3x3 stride-1 launches (zero or reflection padding) with input channels a multiple of 64 and 64
+                             *    or more (or exactly 32) outputs run wgrad3x3_patch_kernel (a staged patch read through ds_read_b64_tr_b16);
+                             *    every other launch runs the fp32 MFMA kernels.  mcav_wgrad_uses_bf16() tells which.
+                             * 3: the split form on every launch the bf16 kernels cover (parity tests).
+                             * (1 takes the same patch kernel in its one-plane form where it applies.) */
 } mcav_wgrad_desc;
 
 size_t mcav_wgrad_workspace_bytes(const mcav_wgrad_desc* d);
