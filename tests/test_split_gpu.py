@@ -318,6 +318,49 @@ def test_second_patch_kernel_matches_float64_as_the_first_one_does(case, tile_bi
     assert errs["second"][3] < 3e-5 and errs["second"][4] < 3e-6, errs
 
 
+@pytest.mark.parametrize("case", [(6, 12, 20, 64, 64, 0), (6, 24, 48, 64, 128, 0), (6, 6, 20, 128, 96, 0), (2, 48, 32, 32, 64, 0), (4, 24, 48, 64, 64, 1),
+                                  (3, 9, 33, 64, 64, 1), (5, 12, 40, 64, 64, 0)])
+def test_twelve_wavefront_patch_kernel_matches_float64_as_the_first_one_does(case):
+    """conv3x3_patch3_kernel (low byte 0x33 of mcav_igemm_desc.tile): three 64-pixel blocks per workgroup, twelve wavefronts, filter tiles in a
+    two-stage ring.  Forward with bias + ReLU, grouped BatchNorm statistics (zero padding), the data gradient -- with reflection padding its
+    adjoint (border extras per block) -- against float64: the same error as the first kernel's; block counts that are no multiple of three."""
+    from mcav import nn as N
+    B, H, W, Cin, Cout, pm = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(1, Cin, 1, 1, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = 0.1 * torch.randn(Cout, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    want = torch.relu(ref_conv64(x, w, b, 1, 1, pm))
+    raw = ref_conv64(x, w, None, 1, 1, pm)
+    xr = x.double().requires_grad_()
+    ref_conv64(xr, w.double(), None, 1, 1, pm).backward(dy.double())
+    grouped = pm == 0 and B % 2 == 0
+    errs = {}
+    for name, tile in (("first", 0), ("twelve", 0x33)):
+        spec = spec_of(w, b, 1, 1, pm, N.MMA_SPLIT_ALL)
+        y = N.conv_fwd(spec, nhwc(x), act=N.ACT_RELU, tile=tile)
+        dx = N.conv_dgrad(spec, nhwc(dy), (H, W), tile=tile)
+        e = [rel_err(nchw(y), want), rel_err(nchw(dx), xr.grad)]
+        rows = 0
+        if grouped:
+            spec0 = spec_of(w, None, 1, 1, pm, N.MMA_SPLIT_ALL)
+            yraw, slab = N.conv_fwd(spec0, nhwc(x), stats=True, groups=2, tile=tile)
+            mt = slab.shape[0] // 2
+            rows = slab.shape[0]
+            s0 = torch.stack([slab[grp * mt:(grp + 1) * mt].double().sum(0).cpu() for grp in range(2)])
+            part = [raw[grp * (B // 2):(grp + 1) * (B // 2)] for grp in range(2)]
+            e += [rel_err(nchw(yraw), raw), max(rel_err(s0[grp][0], part[grp].sum((0, 2, 3))) for grp in range(2)),
+                  max(rel_err(s0[grp][1], (part[grp] ** 2).sum((0, 2, 3))) for grp in range(2))]
+        errs[name] = (e, rows)
+    print("patch kernels %s: first %s | twelve-wavefront %s" % (case, ["%.1e" % v for v in errs["first"][0]], ["%.1e" % v for v in errs["twelve"][0]]))
+    if grouped:
+        assert errs["twelve"][1] < errs["first"][1], "the twelve-wavefront kernel did not run (same statistics rows as the first)"
+        assert errs["twelve"][0][3] < 3e-5 and errs["twelve"][0][4] < 3e-6, errs
+    for es, ef in zip(errs["twelve"][0][:3], errs["first"][0][:3]):
+        assert es < 3e-6 and no_worse(es, ef), errs
+
+
 @pytest.mark.parametrize("case", [(4, 48, 160, 64, 64, 0), (2, 24, 80, 128, 128, 1), (3, 7, 21, 64, 128, 1), (24, 6, 20, 128, 64, 0), (1, 12, 40, 64, 72, 0),
                                   (4, 24, 80, 64, 32, 1)])
 def test_default_mode_weight_gradient_takes_the_patch_kernel_and_matches_float64(case):

@@ -699,6 +699,257 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(IgemmParams p, co
 template <int NS, int TMB>
 constexpr size_t patch_lds_bytes() { return sizeof(u16) * (size_t)NS * (PatchCfg<TMB>::PIX + 3 * 64) * 32 + sizeof(unsigned) * 64 * TMB; }
 
+// ------------------------------------------------------------------------------------------------ patch kernel, twelve-wavefront form (round 4)
+// What the weight-gradient kernel below showed: three wavefronts per SIMD on ONE workgroup per CU hide each other's waits where two workgroups of
+// four did not.  The same block structure as conv3x3_patch_kernel -- a 64-pixel block's patch in LDS per 32-channel chunk, a stage = one filter
+// row -- with THREE blocks per workgroup (192 GEMM rows x 64 outputs): twelve wavefronts, each one 32 x 32 tile of one block; the filter tiles
+// of a stage (37 KB in the split form) serve three blocks (a third of the L2 stream per FLOP of the 64-pixel form) and are staged by 768 threads
+// (12 registers per thread and stage in flight instead of 36) into a TWO-stage ring, so a stage is one barrier (two where the next chunk's
+// patch replaces the current one).  Same epilogue (row offsets in s_out, statistics slab: one row per workgroup = three blocks of one group).
+struct P3Tile {
+    static constexpr int BM = 192, BN = 64, MF = 32, ACC = 16, TM = 1, TN = 1, WAVES_M = 6, WAVES_N = 2;
+    using AccT = f32x16;
+};
+constexpr int P3_THREADS = 768, P3_SUBS = 3, P3_PIX = 110;
+template <int NS> constexpr size_t patch3_lds_bytes() { return sizeof(u16) * (size_t)NS * (P3_SUBS * P3_PIX + 2 * 3 * 64) * 32 + sizeof(unsigned) * 192; }
+#ifndef MCAV_PATCH3_DIAG
+#define MCAV_PATCH3_DIAG 0
+#endif
+
+template <int NS, bool ADJ>
+__global__ __launch_bounds__(P3_THREADS, 1) void conv3x3_patch3_kernel(IgemmParams p, const u16* __restrict__ w16, PatchGeo geo) {
+    using T = P3Tile;
+    constexpr int BN = 64, CKT = 32, LDH = 32, PIX = P3_PIX;
+    constexpr int APL = PIX * LDH, BPL = BN * LDH;               // plane strides in elements
+    constexpr int ASUB = NS * APL, BSTAGE = 3 * NS * BPL;        // one block's patch planes; one ring stage of filter tiles
+    constexpr int diag = MCAV_PATCH3_DIAG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    u16* const Ap = reinterpret_cast<u16*>(s_raw);                                     // [3 blocks][NS][PIX][LDH]
+    u16* const Bs = Ap + P3_SUBS * ASUB;                                               // [2 stages][3 taps][NS][BN][LDH]
+    unsigned* const s_out = reinterpret_cast<unsigned*>(Bs + 2 * BSTAGE);              // [192] byte offset of each row's output pixel
+    float (*const s_stat)[2][BN] = reinterpret_cast<float (*)[2][BN]>(Bs);
+    static_assert(sizeof(u16) * BSTAGE >= sizeof(float) * T::WAVES_M * 2 * BN, "statistics scratch fits a ring stage");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = wave >> 2, wm0 = sub * 64 + ((wave >> 1) & 1) * 32, wn0 = (wave & 1) * 32;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = lid % p.ntiles, mt = lid / p.ntiles;
+    const int n0 = nt * BN;
+    const GatherSrc& g = p.g;
+    const int TH = geo.TH, TW = geo.TW, PW = TW + 2, PH = TH + 2;
+    const int per_img = geo.tiles_y * geo.tiles_x, nblocks = g.B * per_img;
+    const float rcp_pw = 1.0f / (float)PW, rcp_tw = 1.0f / (float)TW;
+    // the workgroup's three blocks (scalars); a block past the last one reads and writes nothing
+    int b_img[P3_SUBS], b_ty0[P3_SUBS], b_tx0[P3_SUBS];
+#pragma unroll
+    for (int sb = 0; sb < P3_SUBS; ++sb) {
+        const int blk = mt * P3_SUBS + sb;
+        const int img = blk / per_img, tr = blk - img * per_img, tyi = tr / geo.tiles_x;
+        b_img[sb] = blk < nblocks ? img : -1;
+        b_ty0[sb] = tyi * TH;
+        b_tx0[sb] = (tr - tyi * geo.tiles_x) * TW;
+    }
+    auto pick = [&](const int (&v)[P3_SUBS], int sb) { return sb == 0 ? v[0] : (sb == 1 ? v[1] : v[2]); };
+
+    if (tid < 192) {
+        const int sb = tid >> 6;
+        const int pix = patch_pixel(tid & 63);
+        const int py = small_div(pix, rcp_tw), px = pix - py * TW;
+        const int img = pick(b_img, sb), y = pick(b_ty0, sb) + py, x = pick(b_tx0, sb) + px;
+        s_out[tid] = (img >= 0 && py < TH && y < p.Hd && x < p.Wd) ? (unsigned)((img * p.Hd + y) * p.Wd + x) * (unsigned)(p.Cd * 4) : OOB;
+    }
+    // patch staging: item = (block, patch pixel, 4 channels): 3 x 110 x 8 items, four per thread
+    constexpr int NJ = (P3_SUBS * PIX * 8 + P3_THREADS - 1) / P3_THREADS;
+    unsigned aoff[NJ], adst[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int item = tid + P3_THREADS * j;
+        const int sb = item / (PIX * 8), rem = item - sb * (PIX * 8), pp = rem >> 3, c4 = rem & 7;
+        const int ppy = small_div(pp, rcp_pw), ppx = pp - ppy * PW;
+        const int sbc = sb < P3_SUBS ? sb : 0;
+        int y = pick(b_ty0, sbc) - 1 + ppy, x = pick(b_tx0, sbc) - 1 + ppx;
+        if (geo.refl == 1) {
+            y = y < 0 ? -y : (y >= g.Hs ? 2 * g.Hs - 2 - y : y);
+            x = x < 0 ? -x : (x >= g.Ws ? 2 * g.Ws - 2 - x : x);
+        }
+        const int img = pick(b_img, sbc);
+        const bool ok = sb < P3_SUBS && img >= 0 && pp < PH * PW && (unsigned)y < (unsigned)g.Hs && (unsigned)x < (unsigned)g.Ws;
+        aoff[j] = ok ? (unsigned)((((img * g.Hs + y) * g.Ws + x) * g.C1 + c4 * 4) * 4) : OOB;
+        adst[j] = sb < P3_SUBS ? (unsigned)(sb * ASUB + pp * LDH + (((c4 >> 1) ^ ((pp >> 2) & 3)) * 8) + (c4 & 1) * 4) : 0xffffffffu;
+    }
+    const unsigned bytes1 = (unsigned)((size_t)g.B * g.Hs * g.Ws * g.C1 * 4);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1, bytes1);
+    const unsigned plane_bytes = (unsigned)((size_t)p.Np_all * p.Kstride * 2);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(w16, (unsigned)((size_t)(p.n_begin + p.n_count) * p.Kstride * 2) + (NS - 1) * plane_bytes);
+    // filter staging: item = (tap of the row, plane, output row, 16-byte piece): 3 NS x 256 items, NS per thread
+    const int bn = (tid & 255) >> 2, bcb = tid & 3, bcombo = tid >> 8;        // this thread's first item: combo = bcombo + 3 j = kx * NS + q
+    const unsigned boff = (n0 + bn < p.n_count) ? (unsigned)(((p.n_begin + n0 + bn) * p.Kstride + bcb * 8) * 2) : OOB;
+    const unsigned bdst = (unsigned)(bn * LDH + ((bcb ^ ((bn >> 2) & 3)) * 8));
+
+    const int nchunks = p.Kp / CKT;
+    auto issueA = [&](f32x4 (&ra)[NJ], int chunk) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) ra[j] = buf_load4s(rs1, aoff[j], chunk * CKT * 4);
+    };
+    auto storeA = [&](const f32x4 (&ra)[NJ]) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (adst[j] != 0xffffffffu) {
+                u16* const dst = Ap + adst[j];
+                if constexpr (NS == 1) {
+                    *reinterpret_cast<u32x2*>(dst) = pack_bf16x4(ra[j]);
+                } else {
+                    const bf16x4 h = __builtin_convertvector(ra[j], bf16x4);
+                    const f32x4 r1 = ra[j] - __builtin_convertvector(h, f32x4);            // exact
+                    const bf16x4 m = __builtin_convertvector(r1, bf16x4);
+                    const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);               // exact
+                    *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, h);
+                    *reinterpret_cast<u32x2*>(dst + APL) = __builtin_bit_cast(u32x2, m);
+                    *reinterpret_cast<u32x2*>(dst + 2 * APL) = pack_bf16x4(r2);
+                }
+            }
+        }
+    };
+    // stage s = chunk * 3 + ky: the filter tiles of taps (ky, 0..2) x planes
+    auto issueB = [&](f32x4 (&rb)[NS], int s) {
+        const int chunk = s / 3, ky = s - chunk * 3;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int combo = bcombo + 3 * j, kx = combo / NS, q = combo - kx * NS;
+            rb[j] = buf_load4s(rsw, boff, ((ky * 3 + kx) * p.Kp + chunk * CKT) * 2 + q * (int)plane_bytes);
+        }
+    };
+    auto storeB = [&](const f32x4 (&rb)[NS], int ring) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) *reinterpret_cast<f32x4*>(Bs + ring * BSTAGE + (bcombo + 3 * j) * BPL + bdst) = rb[j];
+    };
+
+    typename T::AccT acc[1][1], mid, low;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; mid[r] = 0.f; low[r] = 0.f; }
+    const int frow = lane & 31;
+    int prow;
+    unsigned rmask = 0;
+    int my_ty0 = pick(b_ty0, sub), my_tx0 = pick(b_tx0, sub);
+    {
+        const int pix = patch_pixel((wm0 & 63) + frow);
+        const int py = small_div(pix, rcp_tw), px = pix - py * TW;
+        prow = py < TH ? py * PW + px : 0;
+        const int y = my_ty0 + py, x = my_tx0 + px;
+        rmask = (ADJ && py < TH) ? (unsigned)(y == 1) | ((unsigned)(y == p.Hd - 2) << 1) | ((unsigned)(x == 1) << 2) | ((unsigned)(x == p.Wd - 2) << 3) : 0u;
+    }
+    const u16* const Asub = Ap + sub * ASUB;
+    const int fslot = lane >> 5;
+    const int brow = wn0 + frow;
+    const unsigned b_lane0 = (unsigned)(brow * LDH + ((fslot ^ ((brow >> 2) & 3)) * 8));
+    const unsigned b_lane1 = (unsigned)(brow * LDH + (((2 + fslot) ^ ((brow >> 2) & 3)) * 8));
+    const bool fwd = g.sign > 0;
+    const bool has_y1 = ADJ && my_ty0 <= 1 && my_ty0 + TH > 1, has_yl = ADJ && my_ty0 <= p.Hd - 2 && my_ty0 + TH > p.Hd - 2;
+    const bool has_x1 = ADJ && my_tx0 <= 1 && my_tx0 + TW > 1, has_xl = ADJ && my_tx0 <= p.Wd - 2 && my_tx0 + TW > p.Wd - 2;
+    auto mma = [&](const bf16x8 (&a)[NS], const bf16x8 (&b)[NS]) {
+        if constexpr (NS == 1) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[0][0], 0, 0, 0);
+        } else {
+            low = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], low, 0, 0, 0);
+            mid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], mid, 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[0][0], 0, 0, 0);
+            low = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], low, 0, 0, 0);
+            mid = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], mid, 0, 0, 0);
+            low = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], low, 0, 0, 0);
+        }
+    };
+    // the reflection adjoint's extra terms (conv3x3_patch_kernel): border blocks only, after the stage's own steps
+    auto extras = [&](int ky, const u16* Bst) {
+        auto afr = [&](int sky, int skx, int ks, bf16x8 (&a)[NS], bool keep) {
+            const int row = prow + (2 - sky) * PW + 2 - skx;
+            const u16* const ap = Asub + row * LDH + (((2 * ks + fslot) ^ ((row >> 2) & 3)) * 8);
+            const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(ap + q * APL);
+                a[q] = keep ? v : zero;
+            }
+        };
+        const bool yrow = (ky == 0 && has_y1) || (ky == 2 && has_yl);
+        const unsigned ybit = ky == 0 ? 1u : 2u;
+        const int sky = 2 - ky;
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 b[3][NS];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int q = 0; q < NS; ++q) b[kx][q] = *reinterpret_cast<const bf16x8*>(Bst + (ks ? b_lane1 : b_lane0) + (kx * NS + q) * BPL);
+            const unsigned m = rmask;
+            bf16x8 a[NS];
+            if (has_x1) { afr(ky, 2, ks, a, (m & 4u) != 0); mma(a, b[0]); }
+            if (has_xl) { afr(ky, 0, ks, a, (m & 8u) != 0); mma(a, b[2]); }
+            if (yrow) {
+                const bool my = (m & ybit) != 0;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) { afr(sky, kx, ks, a, my); mma(a, b[kx]); }
+                if (has_x1) { afr(sky, 2, ks, a, my && (m & 4u)); mma(a, b[0]); }
+                if (has_xl) { afr(sky, 0, ks, a, my && (m & 8u)); mma(a, b[2]); }
+            }
+        }
+    };
+    // a stage's six steps (three taps x two 16-deep k-steps), fragments of step i + 1 read while the MFMAs of step i run
+    auto compute = [&](int ky, const u16* Bst) {
+        const int rsh = (fwd ? ky : 2 - ky) * PW + (fwd ? 0 : 2);
+        const int dxr = fwd ? 1 : -1;
+        bf16x8 fa[2][NS], fb[2][NS];
+        auto load = [&](int i, bf16x8 (&a)[NS], bf16x8 (&b)[NS]) {
+            const int kx = i >> 1, ks = i & 1;
+            const u16* const bp = Bst + (ks ? b_lane1 : b_lane0) + kx * NS * BPL;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) b[q] = *reinterpret_cast<const bf16x8*>(bp + q * BPL);
+            const int row = prow + rsh + kx * dxr;
+            const u16* const ap = Asub + row * LDH + (((2 * ks + fslot) ^ ((row >> 2) & 3)) * 8);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) a[q] = *reinterpret_cast<const bf16x8*>(ap + q * APL);
+        };
+        load(0, fa[0], fb[0]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i + 1 < 6) load(i + 1, fa[(i + 1) & 1], fb[(i + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(diag & 8)) mma(fa[i & 1], fb[i & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    f32x4 ra[NJ], rbn[NS];
+    const int total = nchunks * 3;
+    issueA(ra, 0);
+    issueB(rbn, 0);
+    storeA(ra);
+    storeB(rbn, 0);
+    if (total > 1) issueB(rbn, 1);
+    __syncthreads();
+    int ky = 0, chunk = 0;
+    for (int s = 0; s < total; ++s) {
+        const bool more = chunk + 1 < nchunks;
+        const u16* const Bst = Bs + (s & 1) * BSTAGE;
+        if (ky == 0 && more && !(diag & 4)) issueA(ra, chunk + 1);               // lands during the chunk's three stages
+        compute(ky, Bst);
+        if constexpr (ADJ) {
+            if (has_y1 | has_yl | has_x1 | has_xl) extras(ky, Bst);
+        }
+        if (s + 1 < total && !(diag & 1)) {                                      // the next stage's filter tiles into the other ring stage (last read before the previous barrier)
+            storeB(rbn, (s + 1) & 1);
+            if (s + 2 < total) issueB(rbn, s + 2);
+        }
+        if (ky == 2 && more && !(diag & 4)) {                                    // the next chunk's patch replaces this one: everybody has to be done reading it
+            __syncthreads();
+            storeA(ra);
+        }
+        __syncthreads();
+        if (++ky == 3) { ky = 0; ++chunk; }
+    }
+    if constexpr (NS > 1) acc[0][0] += mid + low;
+    if (diag & 16) return;
+    igemm_epilogue_lean<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
+}
+
 // ------------------------------------------------------------------------------------------------ patch kernel, second form (round 4)
 // What the counters said about conv3x3_patch_kernel (profiles/r03_pmc_patch_kernel.txt): its MFMA pipe is busy a third of
 // the time because (a) every 64- / 128-pixel block streams the whole filter from L2 (20 B / clk / CU at most, latency-bound by the bytes a
@@ -1191,6 +1442,33 @@ static bool patch_plan(const mcav_igemm_desc* d, PatchGeo& geo, bool f32 = false
     return true;
 }
 
+// Twelve-wavefront form (conv3x3_patch3_kernel): three 64-pixel blocks per workgroup, one workgroup per CU.  The split form only; the three
+// blocks of a workgroup belong to one statistics group.  MCAV_PATCH3 (tune builds) / the low byte 0x33 of mcav_igemm_desc.tile (tests) select it.
+static int patch3_plan(const mcav_igemm_desc* d, PatchGeo& geo) {
+    static const int enabled = MCAV_KNOB_INT("MCAV_PATCH3", 0);       // OFF: ahead per launch on the 12x40 / 24x80 maps, level in the step (profiles/r04_patch3.txt)
+    static const int min_wgs = MCAV_KNOB_INT("MCAV_PATCH3_MIN_WGS", 192);
+    static const int min_k = MCAV_KNOB_INT("MCAV_PATCH3_MIN_K", 128);
+    if (!d || d->mma < 2) return 0;
+    const bool forced = (d->tile & 0xff) == 0x33;
+    if (!enabled && !forced) return 0;
+    PatchGeo g1;
+    if (!patch_plan(d, g1)) return 0;
+    int th, tw;
+    patch_block(d->Hd, d->Wd, 64, P3_PIX, th, tw);
+    geo = g1;
+    geo.TH = th; geo.TW = tw; geo.tmb = 1;
+    geo.tiles_y = (d->Hd + th - 1) / th;
+    geo.tiles_x = (d->Wd + tw - 1) / tw;
+    const long nblk = (long)d->B * geo.tiles_y * geo.tiles_x;
+    if (d->groups > 1 && (nblk / d->groups) % P3_SUBS != 0) return 0;
+    const long wgs = ((nblk + P3_SUBS - 1) / P3_SUBS) * ((d->n_count + 63) / 64);
+    // Where it was measured ahead of the first kernel (batch 12, profiles/r04_patch3.txt): 128 or more channels per tap (four or more chunks: a
+    // workgroup of two chunks lives for six stages and its set-up and epilogue run alone -- the 48x160 maps: 0.083 -> 0.096 ms) and enough
+    // workgroups for one per CU (the 6x20 maps give 128: 0.110 -> 0.117); the 12x40 / 24x80 trunk maps: 0.093 -> 0.079 / 0.085 ms.
+    if (!forced && (wgs < min_wgs || d->Kp < min_k)) return 0;
+    return 1;
+}
+
 // Second form (conv3x3_patch2_kernel): SB = 4 or 2 sub-blocks of 64 pixels per workgroup, one workgroup per CU; 0 = not this form.  The
 // choice is a count of rounds: a launch runs ceil(workgroups / CUs) rounds of SB units of work each, and the fewer sub-blocks win a tie only
 // when they save a round (the filter stream per FLOP doubles with them).  A workgroup's sub-blocks must belong to one statistics group.
@@ -1581,8 +1859,28 @@ int mcav_bf16_igemm(const mcav_igemm_desc* d, hipStream_t s) {
     IgemmParams p;
     int tile;
     // (past this point the caller may have put the bf16 copy into d->w as well: never fall through to the fp32 kernels)
-    PatchGeo geo;
+ PatchGeo geo;
     int bn2 = 64;
+    if (patch3_plan(d, geo)) {
+        dd.tile = 10;
+        if (!fill_params(&dd, p, tile) || p.upm) return MCAV_E_INVALID;
+        if ((long)d->Np * p.Kstride * 2 * 3 >= 0x7fffffffL) return MCAV_E_INVALID;
+        const long nblk = (long)d->B * geo.tiles_y * geo.tiles_x;
+        p.mtiles = (int)((nblk + P3_SUBS - 1) / P3_SUBS);            // rows of the statistics slab = workgroups (three blocks of one group each)
+        p.ntiles = (p.n_count + 63) / 64;
+        static const bool allowed = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch3_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)patch3_lds_bytes<3>()) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_patch3_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)patch3_lds_bytes<3>()) == hipSuccess;
+        }();
+        if (!allowed) return MCAV_E_LAUNCH;
+        const int grid = p.mtiles * p.ntiles;
+        const u16* w16 = reinterpret_cast<const u16*>(d->w16);
+        if (geo.refl == 2) timed_launch(conv3x3_patch3_kernel<3, true>, grid, dim3(P3_THREADS), patch3_lds_bytes<3>(), s, p, w16, geo);
+        else timed_launch(conv3x3_patch3_kernel<3, false>, grid, dim3(P3_THREADS), patch3_lds_bytes<3>(), s, p, w16, geo);
+        return launch_status();
+    }
     if (const int sb = patch2_plan(d, geo, bn2)) {
         dd.tile = 10;
         if (!fill_params(&dd, p, tile) || p.upm) return MCAV_E_INVALID;
@@ -1672,6 +1970,7 @@ int mcav_bf16_igemm_mtiles(const mcav_igemm_desc* d) {
     if (!bt) return 0;
     PatchGeo geo;
     int bn2 = 64;
+    if (patch3_plan(d, geo)) return (int)(((long)d->B * geo.tiles_y * geo.tiles_x + P3_SUBS - 1) / P3_SUBS);
     if (const int sb = patch2_plan(d, geo, bn2)) return (int)(((long)d->B * geo.tiles_y * geo.tiles_x + sb - 1) / sb);
     if (patch_plan(d, geo)) return d->B * geo.tiles_y * geo.tiles_x;
     mcav_igemm_desc dd = *d;
