@@ -99,3 +99,33 @@ def test_batchnorm_finalize_hand_off(nn_kernels):
         assert sum(1 for i in body[first:] if i.startswith("global_load") and " sc1" in i) >= 2, name
         assert any(i.startswith("global_store") and " sc1" in i for i in body[first:]), name
         assert not any(i.startswith(("buffer_wbl2", "buffer_inv")) for i in body), name
+
+
+@pytest.fixture(scope="module")
+def bf16_kernels(tmp_path_factory):
+    return _device_functions(tmp_path_factory, "conv_bf16.hip")
+
+
+def test_transposing_lds_reads_of_the_weight_gradient_kernel_run_with_all_lanes(bf16_kernels):
+    """wgrad3x3_patch_kernel feeds its MFMAs through ds_read_b64_tr_b16, whose gather crosses lanes: the ISA requires EXEC to be all ones (a
+    masked lane's stale address still takes part and the active lanes get wrong data, silently -- cdna_hip_programming.md T10).  The kernel's
+    only divergent code is the guarded staging stores; in the compiled ISA no transposing read may sit between an `s_and_saveexec` and the
+    instruction that restores EXEC, the split-form kernels carry the 96 reads of a block (4 steps x (3 + 9) fragments x 2), and nothing spills."""
+    names = [n for n in bf16_kernels if "wgrad3x3_patch_kernel" in n]
+    assert len(names) == 4, names                      # <3 | 1 planes> x <bias | no bias>
+    for n in names:
+        body = bf16_kernels[n]
+        reads = [i for i, ins in enumerate(body) if ins.startswith("ds_read_b64_tr_b16")]
+        assert len(reads) == (96 if "ILi3E" in n else 32), (n, len(reads))
+        assert not any(ins.startswith("scratch_") for ins in body), n      # no register spills
+        masked = False
+        for ins in body:
+            if ins.startswith("s_and_saveexec_b64") or ins.startswith("s_andn2_saveexec_b64"):
+                masked = True
+            elif re.match(r"s_(or|mov|xor|andn2)_b64 exec,", ins) or ins.startswith(".LBB"):
+                # (a label is a join point: the compiler restores EXEC at it or before the code that follows runs unmasked; the reads of a step
+                # follow the previous step's guarded stores, so the walk must see a restore -- or a join -- before them)
+                if re.match(r"s_(or|mov)_b64 exec,", ins):
+                    masked = False
+            elif ins.startswith("ds_read_b64_tr_b16"):
+                assert not masked, "%s: a transposing LDS read under a partial EXEC mask" % n
