@@ -657,7 +657,7 @@ class _WgradSide:
     that for gradients it accumulates itself, and these networks write their parameter gradients straight into the arena."""
 
     def __init__(self):
-        self.enabled = True
+        self.enabled = _os.environ.get("MCAV_WGRAD_SIDE", "1") != "0"      # (0: weight gradients in line on the calling stream -- A/B timing)
         self.stream = None
         self.keep = []
         self.mains = []            # streams a network backward ran on during this backward pass
