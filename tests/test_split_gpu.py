@@ -396,3 +396,34 @@ def test_default_mode_weight_gradient_takes_the_patch_kernel_and_matches_float64
     spec = spec_of(torch.randn(64, 32, 3, 3, generator=g) * 0.05, None, 1, 1, 0, N.MMA_SPLIT)
     N.conv_wgrad(spec, torch.randn(2, 12, 20, 32, generator=g).to(DEV), torch.randn(2, 12, 20, 64, generator=g).to(DEV))
     assert N.LAST_WGRAD_PLANES == 0
+
+
+@pytest.mark.parametrize("B,H,W", [(4, 64, 128), (2, 45, 70), (6, 192, 640)])
+def test_split_depth_stem_matches_float64_as_the_fp32_stem_kernel_does(B, H, W):
+    """The depth net's image stem (conv 7x7 stride 2, 3 -> 64 on the NHWC4 image; reference resnet_dispnet.py: torchvision conv1) in the split
+    form (mma = 3; measured level with the fp32 stem kernel, so the default mode keeps that one): stem7x7s2_split_fwd_kernel -- 14 k-steps of the bf16 MFMA on three planes per operand, every A fragment one aligned 16-byte
+    read of the staged image patch -- against float64, no worse than the fp32 stem kernel; BatchNorm statistics of two stacked passes; whole,
+    ragged and full-size maps."""
+    from mcav import nn as N
+    g = torch.Generator().manual_seed(15 + H)
+    x = torch.randn(B, 3, H, W, generator=g) * torch.tensor([1.0, 0.05, 4.0]).view(1, 3, 1, 1)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1 * torch.exp(torch.randn(64, 1, 1, 1, generator=g))
+    want = F.conv2d(x.double(), w.double(), None, stride=2, padding=3)
+    x4 = N.nchw_to_nhwc(x.to(DEV), 4)
+    groups = 2 if B % 2 == 0 else 1
+    errs = {}
+    for name, mma in (("fp32", N.MMA_FP32), ("split", N.MMA_SPLIT_ALL)):
+        spec = N.ConvSpec(torch.nn.Parameter(w.to(DEV)), None, 2, 3, 0, smallc=True)
+        spec.mma = mma
+        got, slab = N.conv_fwd(spec, x4, stats=True, groups=groups)
+        assert getattr(spec, "_stem", None) is not None
+        mt = slab.shape[0] // groups
+        e = [rel_err(nchw(got), want), rms_err(nchw(got), want)]
+        for grp in range(groups):
+            s_ = slab[grp * mt:(grp + 1) * mt].double().sum(0).cpu()
+            part = want[grp * (B // groups):(grp + 1) * (B // groups)]
+            e += [rel_err(s_[0], part.sum((0, 2, 3))), rel_err(s_[1], (part ** 2).sum((0, 2, 3)))]
+        errs[name] = e
+    print("depth stem %s: split %s | fp32 %s" % ((B, H, W), ["%.1e" % v for v in errs["split"]], ["%.1e" % v for v in errs["fp32"]]))
+    assert errs["split"][0] < 3e-6 and (no_worse(errs["split"][0], errs["fp32"][0]) or errs["split"][1] <= 1.25 * errs["fp32"][1]), errs
+    assert all(v < 1e-4 for v in errs["split"][2:]), errs

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, 2) void stem7x7s2_fwd_kernel(IgemmParams p, co
     constexpr int C = S::C, PR = S::PR, KS = S::KS, TM = S::TM, TN = S::TN, NW = S::NW, TH = S::TH;
     __shared__ __attribute__((aligned(16))) float sP[C][PR][2][ST_PC];
     __shared__ __attribute__((aligned(16))) float sW[2 * KS][NW];
-    __shared__ int s_out[TH * 32];
+    __shared__ __attribute__((aligned(16))) unsigned s_out[TH * 32];      // byte offset of each tile row's output pixel (OOB: none): the lean epilogue's form
     using E = typename S::Epi;
     float (*const s_stat)[2][E::BN] = reinterpret_cast<float (*)[2][E::BN]>(&sP[0][0][0][0]);      // free once the K loop is done
     static_assert(sizeof(float) * C * PR * 2 * ST_PC >= sizeof(float) * 4 * 2 * E::BN, "statistics scratch fits the patch");
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void stem7x7s2_fwd_kernel(IgemmParams p, co
         __syncthreads();                                  // the previous tile's epilogue is done with s_out and the statistics scratch
         if (tid < TH * 32) {   // destination pixel of every tile row (row = (TM wave + i) * 32 + px)
             const int r = tid, oy = oy0 + (r >> 5), ox = ox0 + (r & 31);
-            s_out[r] = (oy < p.Hd && ox < p.Wd) ? (b * p.Hd + oy) * p.Wd + ox : -1;
+            s_out[r] = (oy < p.Hd && ox < p.Wd) ? (unsigned)((b * p.Hd + oy) * p.Wd + ox) * (unsigned)(p.Cd * 4) : OOB;
         }
 #pragma unroll
         for (int j = 0; j < PN; ++j) {
@@ -135,7 +135,170 @@ __global__ __launch_bounds__(256, 2) void stem7x7s2_fwd_kernel(IgemmParams p, co
             __builtin_amdgcn_sched_barrier(0);
         });
         __syncthreads();                                  // every wavefront is done with the patch: its memory becomes the statistics scratch
-        igemm_epilogue<E>(p, acc, s_out, s_stat, tid, wave * TM * 32, 0, 0, mt);
+        // (the lean epilogue since round 4: raw buffer stores, no per-element branch or 64-bit address arithmetic -- the stem kernels were bound by
+        // their epilogue, not by the MFMAs: 0.18 of the depth stem's 0.23 ms remained with the K loop removed)
+        igemm_epilogue_lean<E>(p, acc, s_out, s_stat, tid, wave * TM * 32, 0, 0, mt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the depth stem as an fp32 contraction on split operands (round 4)
+// The fp32 kernel above needs 84 v_mfma_f32_32x32x2_f32 per 32 x 32 tile (100 us of MFMA issue for the step's 24 images) and runs at 232 us.  The
+// same contraction on three bf16 planes per operand (six plane products, fp32 accumulation; mcav_igemm_desc.mma >= 2) is 14
+// k-steps of v_mfma_f32_32x32x16_bf16: with the K order (ky, kx 0..7, channel 0..3) a lane's 8 consecutive k are two source pixels x four
+// channels = 16 contiguous bytes of the NHWC4 image row, and because the stride is 2 and a pixel is 4 channels, output pixel px starts
+// 16 px bytes into the row: every A fragment is ONE aligned ds_read_b128 of the staged patch (no im2col), conflict-free across the 32
+// pixels of a fragment.  The filter slice (64 outputs x 224 k x 3 planes, 87 KB) is split once per persistent workgroup from the packed
+// fp32 copy the fp32 kernel uses.  One workgroup per CU (125 KB of LDS), four wavefronts of 2 x 2 tiles, ONE accumulator per tile.
+typedef __bf16 st_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 st_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short st_u16;
+typedef unsigned int st_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int SS_TH = 8, SS_PR = 2 * SS_TH + 5, SS_PCOL = 72, SS_PROW = SS_PCOL * 4;      // patch: 21 rows x 72 pixels x 4 channels (288 bf16 per row)
+constexpr int SS_K = 224, SS_WROW = 232;                      // filter row of an output channel, padded: rows 116 dwords apart (conflict-free ds_read_b128)
+constexpr int SS_PPL = SS_PR * SS_PROW, SS_WPL = 64 * SS_WROW;      // plane strides (elements)
+#ifndef MCAV_SS_DIAG
+#define MCAV_SS_DIAG 0                                    // timing experiments only, WRONG results: 1 no MFMAs, 2 no epilogue
+#endif
+constexpr int SS_DIAG = MCAV_SS_DIAG;
+constexpr size_t stem_split_lds_bytes() { return sizeof(st_u16) * 3 * (size_t)(SS_PPL + SS_WPL) + sizeof(unsigned) * SS_TH * 32; }
+
+__device__ __forceinline__ void st_split3(f32x4 v, st_u32x2& h, st_u32x2& m, st_u32x2& l) {
+    const st_bf16x4 hb = __builtin_convertvector(v, st_bf16x4);
+    const f32x4 r1 = v - __builtin_convertvector(hb, f32x4);                  // exact
+    const st_bf16x4 mb = __builtin_convertvector(r1, st_bf16x4);
+    const f32x4 r2 = r1 - __builtin_convertvector(mb, f32x4);                 // exact
+    const st_bf16x4 lb = __builtin_convertvector(r2, st_bf16x4);
+    h = __builtin_bit_cast(st_u32x2, hb); m = __builtin_bit_cast(st_u32x2, mb); l = __builtin_bit_cast(st_u32x2, lb);
+}
+
+__global__ __launch_bounds__(256, 1) void stem7x7s2_split_fwd_kernel(IgemmParams p, const float* __restrict__ wk, int tiles_x, int tiles_y) {
+    using S = StemDepth;
+    using E = typename S::Epi;
+    constexpr int TM = S::TM, TN = S::TN, TH = S::TH;
+    static_assert(TH == SS_TH && TM == 2 && TN == 2, "8 output rows per tile, 2 x 2 tiles per wavefront");
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    st_u16* const sP = reinterpret_cast<st_u16*>(s_raw);                       // [3][SS_PR][SS_PROW]
+    st_u16* const sW = sP + 3 * SS_PPL;                                        // [3][64][SS_WROW]
+    unsigned* const s_out = reinterpret_cast<unsigned*>(sW + 3 * SS_WPL);     // [TH * 32] byte offset of each tile row's output pixel (OOB: none)
+    float (*const s_stat)[2][E::BN] = reinterpret_cast<float (*)[2][E::BN]>(sP);      // free once the K loop is done
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per_img = tiles_x * tiles_y, ntiles = p.g.B * per_img;
+    const GatherSrc& g = p.g;
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(g.x1, (unsigned)((size_t)g.B * g.Hs * g.Ws * S::CP * 4));
+
+    // ---- the filter slice, once per (persistent) workgroup: packed fp32 copy [(c * 7 + ky) * 8 + kx][64] -> three planes [64][(ky, kx, c)]
+    constexpr int WN = 64 * SS_K / 256;                   // 56 elements per thread: all loads in flight before the first use
+    float wv[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int e = tid + 256 * j, co = e & 63, k = e >> 6, ky = k >> 5, kx = (k >> 2) & 7, c = k & 3;
+        wv[j] = c < 3 ? wk[((c * 7 + ky) * 8 + kx) * 64 + co] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int e = tid + 256 * j, co = e & 63, k = e >> 6;
+        const float v = wv[j];
+        const __bf16 hb = (__bf16)v;
+        const float r1 = v - (float)hb;
+        const __bf16 mb = (__bf16)r1;
+        const __bf16 lb = (__bf16)(r1 - (float)mb);
+        sW[co * SS_WROW + k] = __builtin_bit_cast(st_u16, hb);
+        sW[SS_WPL + co * SS_WROW + k] = __builtin_bit_cast(st_u16, mb);
+        sW[2 * SS_WPL + co * SS_WROW + k] = __builtin_bit_cast(st_u16, lb);
+    }
+    // ---- a tile's input patch: source rows 2 oy0 - 3 .., pixels 2 ox0 - 3 ..; out-of-image pixels read as zero (zero padding)
+    constexpr int PN = (SS_PR * SS_PCOL + 255) / 256;
+    f32x4 pv[PN];
+    auto issue = [&](int t) {
+        const int b = t / per_img, tr = t - b * per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int sy0 = 2 * ty * TH - 3, sx0 = 2 * tx * ST_TW - 3;
+#pragma unroll
+        for (int j = 0; j < PN; ++j) {
+            const int i = tid + 256 * j;
+            const int row = i / SS_PCOL, col = i - row * SS_PCOL;
+            const int sy = sy0 + row, sx = sx0 + col;
+            const bool ok = t < ntiles && i < SS_PR * SS_PCOL && (unsigned)sy < (unsigned)g.Hs && (unsigned)sx < (unsigned)g.Ws;
+            pv[j] = buf_load4(rsx, ok ? (unsigned)(((b * g.Hs + sy) * g.Ws + sx) * S::CP * 4) : OOB);
+        }
+    };
+    const int px = lane & 31, h = lane >> 5;
+    // lane-constant bases (elements): output row 2 wave + i reads patch row 2 (2 wave + i) + ky; pixel px starts 8 px elements into the row
+    const st_u16* const pa = sP + (4 * wave) * SS_PROW + 8 * px + 8 * h;
+    const st_u16* const pb = sW + px * SS_WROW + 8 * h;
+
+    issue(blockIdx.x);
+    for (int mt = blockIdx.x; mt < ntiles; mt += gridDim.x) {
+        const int b = mt / per_img, tr = mt - b * per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * ST_TW;
+        __syncthreads();                                  // the previous tile's epilogue is done with s_out and the statistics scratch (and the filter slice is stored)
+        if (tid < TH * 32) {
+            const int r = tid, oy = oy0 + (r >> 5), ox = ox0 + (r & 31);
+            s_out[r] = (oy < p.Hd && ox < p.Wd) ? (unsigned)((b * p.Hd + oy) * p.Wd + ox) * (unsigned)(p.Cd * 4) : OOB;
+        }
+#pragma unroll
+        for (int j = 0; j < PN; ++j) {
+            const int i = tid + 256 * j;
+            if (i < SS_PR * SS_PCOL) {
+                st_u32x2 hh, mm, ll;
+                st_split3(pv[j], hh, mm, ll);
+                *reinterpret_cast<st_u32x2*>(sP + i * 4) = hh;
+                *reinterpret_cast<st_u32x2*>(sP + SS_PPL + i * 4) = mm;
+                *reinterpret_cast<st_u32x2*>(sP + 2 * SS_PPL + i * 4) = ll;
+            }
+        }
+        __syncthreads();
+        issue(mt + gridDim.x);                            // (past the last tile: out-of-range offsets, no memory traffic)
+
+        f32x16 acc[TM][TN], mid[TM][TN], low[TM][TN];     // (one wavefront per SIMD: the register file has room for the small terms' own accumulators)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; mid[i][j][r] = 0.f; low[i][j][r] = 0.f; }
+        // 14 k-steps (ky, half of the row's eight pixels); fragments of step s + 1 are read before the MFMAs of step s are issued
+        st_bf16x8 fa[2][TM][3], fb[2][TN][3];
+        auto rd = [&](auto sc) {
+            constexpr int ks = decltype(sc)::value, ky = ks >> 1, kh = ks & 1, sl = ks & 1;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fa[sl][i][q] = *reinterpret_cast<const st_bf16x8*>(pa + q * SS_PPL + (2 * i + ky) * SS_PROW + 16 * kh);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fb[sl][j][q] = *reinterpret_cast<const st_bf16x8*>(pb + q * SS_WPL + 32 * j * SS_WROW + 32 * ky + 16 * kh);
+        };
+        rd(std::integral_constant<int, 0>{});
+        static_for<14>([&](auto sc) {
+            constexpr int ks = decltype(sc)::value, sl = ks & 1;
+            if constexpr (ks + 1 < 14) rd(std::integral_constant<int, ks + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const st_bf16x8(&a)[3] = fa[sl][i];
+                    const st_bf16x8(&bq)[3] = fb[sl][j];
+                    if (SS_DIAG & 1) continue;
+                    low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bq[0], low[i][j], 0, 0, 0);
+                    mid[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[0], mid[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], acc[i][j], 0, 0, 0);
+                    low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[2], low[i][j], 0, 0, 0);
+                    mid[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[1], mid[i][j], 0, 0, 0);
+                    low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[1], low[i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += mid[i][j] + low[i][j];
+        __syncthreads();                                  // every wavefront is done with the patch: its memory becomes the statistics scratch
+        if (!(SS_DIAG & 2)) igemm_epilogue_lean<E>(p, acc, s_out, s_stat, tid, wave * TM * 32, 0, 0, mt);
     }
 }
 
@@ -322,6 +485,18 @@ bool mcav_try_stem(const mcav_igemm_desc* d, const IgemmParams& p, hipStream_t s
     IgemmParams q = p;
     q.groups = 1;                                         // (the statistics rows of a tile are image-major: groups need nothing else)
     const int ntiles = d->B * tiles_x * tiles_y;
+    // The split form of the depth stem: measured 0.189 ms against the fp32 kernel's 0.179 (both with the lean epilogue; 24 x 192 x 640): the stem is
+    // bound by its patch staging and its 189 MB of output stores, which the split kernel's ONE workgroup per CU (125 KB of LDS) has nothing to
+    // overlap with, while its MFMAs take 0.06 instead of 0.10 ms.  OFF under the default mode (mma = 2); mma = 3 (the parity tests) runs it.
+    static const int split_on = MCAV_KNOB_INT("MCAV_STEM_SPLIT", 0);
+    if (kind == 1 && (d->mma == 3 || (d->mma == 2 && split_on))) {
+        static const bool allowed = hipFuncSetAttribute(reinterpret_cast<const void*>(stem7x7s2_split_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)stem_split_lds_bytes()) == hipSuccess;
+        if (allowed) {
+            timed_launch(stem7x7s2_split_fwd_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(256), stem_split_lds_bytes(), s, q, d->w_stem, tiles_x, tiles_y);
+            return true;
+        }
+    }
     const dim3 grid(ntiles < 512 ? ntiles : 512);         // persistent: 2 per CU
     if (kind == 1) timed_launch(stem7x7s2_fwd_kernel<StemDepth>, grid, dim3(256), 0, s, q, d->w_stem, tiles_x, tiles_y);
     else timed_launch(stem7x7s2_fwd_kernel<StemPose>, grid, dim3(256), 0, s, q, d->w_stem, tiles_x, tiles_y);
