@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p, const u1
     constexpr int NB = NS == 1 ? 2 : 1;                           // LDS panels; indexed [NB * NS]: buffer b of the plain form = plane 0 of panel b
     __shared__ __attribute__((aligned(16))) u16 As[NB * NS][BM][T::LDH];
     __shared__ __attribute__((aligned(16))) u16 Bs[NB * NS][BN][T::LDH];
-    __shared__ int s_out[BM];
+    __shared__ __attribute__((aligned(16))) unsigned s_out[BM];      // byte offset of each row's output pixel (OOB: none): the lean epilogue's form
     float (*const s_stat)[2][BN] = reinterpret_cast<float (*)[2][BN]>(&As[1][0][0]);
     static_assert(sizeof(u16) * BM * T::LDH >= sizeof(float) * T::WAVES_M * 2 * BN, "statistics scratch fits one A buffer");
     extern __shared__ unsigned s_dyn[];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p, const u1
         const bool ok = decode_row(p, m0 + r, n, dy, dx);
         int o = -1;
         if (ok) o = p.pool ? ((n * (p.Hd >> 1) + (dy >> 1)) * (p.Wd >> 1) + (dx >> 1)) : ((n * p.Hd + dy) * p.Wd + dx);
-        s_out[r] = o;
+        s_out[r] = ok ? (unsigned)o * (unsigned)(p.Cd * 4) : OOB;
         s_rn[r] = ok ? n : -1; s_ry[r] = dy; s_rx[r] = dx;
     }
     if (tid == 0) {
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(IgemmParams p, const u1
 #pragma unroll
             for (int j = 0; j < T::TN; ++j) acc[i][j] += mid[i][j] + low[i][j];
     }
-    igemm_epilogue<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);
+    igemm_epilogue_lean<T>(p, acc, s_out, s_stat, tid, wm0, wn0, n0, mt);      // (round 4: raw buffer stores instead of a branch and a 64-bit address per element)
 }
 
 // ------------------------------------------------------------------------------------------------ 3x3 stride-1 zero-padded conv, patch in LDS
