@@ -462,8 +462,9 @@ def conv_fwd(spec, x1, x2=None, up1=False, act=ACT_NONE, stats=False, tile=0, gr
     _weights_for(spec, d, False)
     if spec.is_stem() and not stats_blocks_stem(spec, stats) and x2 is None and not up1 and not (tile >> 9) & 1:
         d.w_stem = P(spec.packed_stem())               # a 7x7 stride-2 stem: patch-in-LDS kernel (tile bit 9 keeps the general one)
-        if spec.mma >= MMA_SPLIT and spec.smallc and spec.cout == 64:
-            d.mma = spec.mma                           # the depth stem as an fp32 contraction on split operands (stem7x7s2_split_fwd_kernel splits the packed fp32 slice itself)
+        if spec.mma == MMA_SPLIT_ALL and spec.smallc and spec.cout == 64:
+            d.mma = spec.mma                           # the depth stem in the split form (stem7x7s2_split_fwd_kernel splits the packed fp32 slice itself): level with
+                                                       # the fp32 stem kernel, so only "every launch on the split kernels" (the parity tests) takes it
     if (up1 and x2 is not None and not stats and spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad == 1
             and spec.pad_mode == PAD_REFLECT and C1 % 16 == 0 and not (tile >> 11) & 1 and not d.mma):
         d.w_upmerge = P(spec.packed_upmerge(C1))       # the upsampled part as 4 merged taps on the low-resolution x1 (tile bit 11: off)
