@@ -163,7 +163,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams p) {
         }
     }
 
-    // ---- epilogue.  C/D layout 16x16: column = lane & 15 (output channel), rows 4 (lane >> 4) + e (pixel column within the fragment)
+    // ---- epilogue.  C/D layout 16x16: column = lane & 15 (output channel), rows 4 (lane >> 4) + e (pixel column within the fragment).
+    // Raw buffer accesses (round 4: an out-of-range element gets the OOB offset and is dropped in hardware -- no branch and no 64-bit address per
+    // element; the tensors are < 2 GiB, checked on the host).
+    const unsigned ybytes = (unsigned)((size_t)p.B * ((ADJ && p.pool) ? (p.H >> 1) * (p.W >> 1) : p.H * p.W) * p.Cd * 4);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, ybytes);
+    const __amdgpu_buffer_rsrc_t rax = make_rsrc(p.dact_aux ? p.dact_aux : p.y, ybytes);
+    const __amdgpu_buffer_rsrc_t rad = make_rsrc(p.addend ? p.addend : p.y, ybytes);
 #pragma unroll
     for (int h = 0; h < NF; ++h) {
         const int co = p.co0 + h * 16 + nn;
@@ -177,13 +183,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams p) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int ox = (x0 >> 1) + 8 * f + 2 * g + e;
-                    if (cok && oy < (p.H >> 1) && ox < (p.W >> 1)) {
-                        float v = (acc[f][h][2 * e] + acc[f][h][2 * e + 1]) + (acc[f + 2][h][2 * e] + acc[f + 2][h][2 * e + 1]);
-                        const size_t off = ((size_t)(n * (p.H >> 1) + oy) * (p.W >> 1) + ox) * p.Cd + co;
-                        if (p.dact_aux) v *= act_bwd(p.dact_aux[off], p.dact);
-                        if (p.addend) v += p.addend[off];
-                        p.y[off] = v;
-                    }
+                    const bool ok = cok && oy < (p.H >> 1) && ox < (p.W >> 1);
+                    float v = (acc[f][h][2 * e] + acc[f][h][2 * e + 1]) + (acc[f + 2][h][2 * e] + acc[f + 2][h][2 * e + 1]);
+                    const unsigned off = ok ? (unsigned)((((n * (p.H >> 1) + oy) * (p.W >> 1) + ox) * p.Cd + co) * 4) : OOB;
+                    if (p.dact_aux) v *= act_bwd(buf_load1(rax, off), p.dact);
+                    if (p.addend) v += buf_load1(rad, off);
+                    buf_store1(ry, off, v);
                 }
             }
         } else {
@@ -193,15 +198,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int ox = x0 + 16 * (f & 1) + 4 * g + e;
-                    if (cok && oy < p.H && ox < p.W) {
-                        const size_t off = ((size_t)(n * p.H + oy) * p.W + ox) * p.Cd + co;
-                        float v = act_fwd(acc[f][h][e] + bv, p.act);
-                        if (ADJ) {
-                            if (p.dact_aux) v *= act_bwd(p.dact_aux[off], p.dact);
-                            if (p.addend) v += p.addend[off];
-                        }
-                        p.y[off] = v;
+                    const bool ok = cok && oy < p.H && ox < p.W;
+                    const unsigned off = ok ? (unsigned)((((n * p.H + oy) * p.W + ox) * p.Cd + co) * 4) : OOB;
+                    float v = act_fwd(acc[f][h][e] + bv, p.act);
+                    if (ADJ) {
+                        if (p.dact_aux) v *= act_bwd(buf_load1(rax, off), p.dact);
+                        if (p.addend) v += buf_load1(rad, off);
                     }
+                    buf_store1(ry, off, v);
                 }
             }
         }
