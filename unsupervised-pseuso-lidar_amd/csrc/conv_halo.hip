@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_up_kernel(HaloParams p) {
                     }
                 }
     }
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, (unsigned)((size_t)p.B * p.H * p.W * p.Cd * 4));
 #pragma unroll
     for (int h = 0; h < NF; ++h) {
         const int co = p.co0 + h * 16 + nn;
@@ -322,7 +323,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_up_kernel(HaloParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ox = x0 + 2 * (4 * g + e) + (f & 1);
-                if (cok && oy < p.H && ox < p.W) p.y[((size_t)(n * p.H + oy) * p.W + ox) * p.Cd + co] = act_fwd(acc[f][h][e] + bv, p.act);
+                const bool ok = cok && oy < p.H && ox < p.W;
+                buf_store1(ry, ok ? (unsigned)((((n * p.H + oy) * p.W + ox) * p.Cd + co) * 4) : OOB, act_fwd(acc[f][h][e] + bv, p.act));
             }
         }
     }
